@@ -1,0 +1,233 @@
+/* raytracer_amd.h -- C-ABI of libraytracer_amd.so, the MI355X (gfx950) render loop.
+ *
+ * The reference (Basemism/Raytracer) has no plugin/FFI API.  Its only seam is the pair of
+ * member calls made once from main():
+ *
+ *     rayTracer.renderPathTrace(outputFilename) / rayTracer.render(outputFilename)
+ *                                   -- /root/reference/src/RayTracer.cpp:146-149
+ *
+ * after the setters at RayTracer.cpp:129-139.  Everything a replacement needs at that seam is
+ * plain data: Scene::objects / lights / backgroundColor / bvhRoot-or-null (include/Scene.h:17-21),
+ * the Camera constants (include/Camera.h:11-26) and the RayTracer scalars
+ * (include/RayTracer.h:35-47).  This header states that data as POD structs and the calls as
+ * extern "C" functions: plain pointers and sizes, no C++ types, no exceptions across the
+ * boundary.  Every function returns 0 on success and a negative rt_status on failure;
+ * rt_last_error() returns a thread-local message for the last failing call.
+ *
+ * Conventions
+ *   - All arithmetic on the path is IEEE binary64, as in the reference (include/Vector3.h:14).
+ *   - Primitive ID = index in Scene::objects = order of the JSON "shapes" array with unsupported
+ *     types skipped (RayTracer.cpp:931-999, Scene.cpp:15-17).  -1 = miss.
+ *   - Image buffers are row-major, row j = 0 is the BOTTOM row (the writer emits j = H-1 first,
+ *     RayTracer.cpp:356), pixel (i, j) at rgb[(j*W + i)*3 .. +2].
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,  /* bad argument / inconsistent sizes                     */
+    RT_ERR_IO = -2,       /* file could not be opened / parsed                      */
+    RT_ERR_DEVICE = -3,   /* HIP runtime error or no gfx950 device / kernel missing */
+    RT_ERR_STATE = -4,    /* call order (render before upload, ...)                 */
+    RT_ERR_LIMIT = -5     /* a documented size limit was exceeded                   */
+} rt_status;
+
+/* Intersectable subclasses (include/Sphere.h, Triangle.h, Cylinder.h). */
+enum { RT_SPHERE = 0, RT_TRIANGLE = 1, RT_CYLINDER = 2 };
+/* RayTracer::RenderMode, same numbering (include/RayTracer.h:15). */
+enum { RT_MODE_PHONG = 0, RT_MODE_BINARY = 1, RT_MODE_PATHTRACE = 2 };
+/* RayTracer::ToneMapping, same numbering (include/RayTracer.h:16). */
+enum { RT_TONEMAP_NONE = 0, RT_TONEMAP_REINHARD = 1, RT_TONEMAP_WARD = 2, RT_TONEMAP_UNCHARTED2 = 3 };
+/* Light::LightType (include/Light.h:11-14). */
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+
+/* One geometry row per primitive, RT_GEOM_STRIDE doubles, holding the CONSTRUCTOR ARGUMENTS of
+ * the reference class (the library applies what the constructors do):
+ *   sphere   : center xyz, radius                              (src/Sphere.cpp:9-10)
+ *   triangle : v0 xyz, v1 xyz, v2 xyz; the normal is derived as in src/Triangle.cpp:7-12
+ *   cylinder : baseCenter xyz, axis xyz, radius, height -- i.e. AFTER the parse transform of
+ *              RayTracer.cpp:987-989; the constructor's own axis.normalize()
+ *              (src/Cylinder.cpp:11) is applied by the library.
+ * Unused slots are ignored. */
+#define RT_GEOM_STRIDE 12
+
+/* Material (include/Material.h:12-26).  texture = index into rt_scene_desc.textures or -1. */
+typedef struct rt_material {
+    double ks, kd;
+    double reflectivity, refractive_index;
+    double diffuse[3];
+    double specular[3];
+    int32_t specular_exponent; /* int in the reference (Material.h:14) */
+    int32_t is_reflective;
+    int32_t is_refractive;
+    int32_t texture;
+} rt_material;
+
+/* Texture as loaded by Material::loadTexture (src/Material.cpp:17-67): 8-bit RGB, row 0 first.
+ * The reference stores byte/255.0 as f64; the device divides on fetch, same value. */
+typedef struct rt_texture {
+    int32_t width, height;
+    const uint8_t* rgb; /* width*height*3 bytes */
+} rt_texture;
+
+/* PointLight / AreaLight constructor arguments (include/PointLight.h:12, AreaLight.h:18-22);
+ * the library normalizes normal/u/v as the AreaLight constructor does. */
+typedef struct rt_light {
+    int32_t type;
+    int32_t reserved;
+    double intensity[3];
+    double position[3]; /* area light: rectangle CENTRE */
+    double normal[3];
+    double u[3];
+    double v[3];
+    double width, height;
+} rt_light;
+
+/* Scene at the seam (include/Scene.h:17-21). */
+typedef struct rt_scene_desc {
+    int32_t n_prims;
+    int32_t n_materials;
+    int32_t n_textures;
+    int32_t n_lights;
+    const int32_t* prim_type;     /* [n_prims] RT_SPHERE / RT_TRIANGLE / RT_CYLINDER            */
+    const int32_t* prim_material; /* [n_prims] index into materials                              */
+    const double* prim_geom;      /* [n_prims][RT_GEOM_STRIDE]                                   */
+    const rt_material* materials; /* [n_materials]                                               */
+    const rt_texture* textures;   /* [n_textures]                                                */
+    const rt_light* lights;       /* [n_lights]                                                  */
+    double background[3];         /* Scene::backgroundColor                                      */
+    int32_t use_bvh;              /* bvhRoot built (RayTracer.cpp:95-99) -> "last leaf wins ties"
+                                     (BVHNode.cpp:64-69); 0 -> linear scan, first object wins
+                                     (Scene.cpp:72-78)                                           */
+    int32_t reserved;
+} rt_scene_desc;
+
+/* Camera constants as left by the Camera constructor (src/Camera.cpp:9-31). */
+typedef struct rt_camera {
+    double position[3];
+    double lower_left[3];
+    double horizontal[3];
+    double vertical[3];
+    double u[3];
+    double v[3];
+    double lens_radius;
+} rt_camera;
+
+/* RayTracer scalars (include/RayTracer.h:35-47) plus the partition of one frame over GPUs. */
+typedef struct rt_params {
+    int32_t width, height;
+    int32_t mode;          /* RT_MODE_*                                                        */
+    int32_t tonemap;       /* RT_TONEMAP_*                                                     */
+    int32_t max_depth;     /* RayTracer::maxDepth ("nbounces")                                 */
+    int32_t pixel_samples; /* RayTracer::pixelSamples AS SET, i.e. after the swap at
+                              RayTracer.cpp:138-139 (JSON "lightsample")                       */
+    int32_t light_samples; /* RayTracer::lightSamples AS SET (JSON "pixelsample")              */
+    int32_t reserved0;
+    double exposure;
+    double shadow_bias; /* 1e-4, include/RayTracer.h:41 */
+    uint64_t seed;      /* key of the counter-based RNG (path trace only)                     */
+    /* Row-band partition (Whitted/binary and path trace): the frame is cut into bands of
+     * band_rows rows; this call renders bands b with b % band_world == band_rank and stores
+     * them compactly (local band b / band_world).  band_world = 1 renders the full frame. */
+    int32_t band_rows;
+    int32_t band_rank;
+    int32_t band_world;
+    /* Sample-range partition (path trace): strata indices s = sy*sqrt_nspp + sx in
+     * [sample_begin, sample_end); sample_end <= 0 means "all". */
+    int32_t sample_begin;
+    int32_t sample_end;
+    int32_t reserved1;
+} rt_params;
+
+typedef struct rt_stats {
+    uint64_t rays;         /* closest-hit queries traced by the last render (= Scene::intersect
+                              calls the reference would make, src/Scene.cpp:63)                */
+    uint64_t box_tests;    /* BoundingBox::intersect evaluations actually executed            */
+    uint64_t prim_tests;   /* primitive intersect evaluations actually executed               */
+    double kernel_ms;      /* HIP-event time of the last render's kernels on their stream     */
+    double upload_ms;      /* last scene upload (host flatten + H2D)                           */
+    int32_t n_bvh_nodes;   /* flattened BVH nodes (0 in linear mode)                           */
+    int32_t scene_in_lds;  /* 1 if the scene image was staged in LDS                           */
+} rt_stats;
+
+typedef struct rt_context rt_context;       /* device-side renderer, one per GPU             */
+typedef struct rt_scene_file rt_scene_file; /* host-side result of the JSON ingest           */
+
+/* ---- errors ------------------------------------------------------------------------------ */
+const char* rt_last_error(void);
+int rt_api_version(void);
+
+/* ---- host ingest: what main() does before the seam (RayTracer.cpp:52-143, 817-1035) ------- */
+/* Parses the scene JSON exactly as the reference does (defaults, the cylinder transform, the
+ * pixelsample/lightsample swap, texture loading relative to the cwd).  tonemap_name is argv[3]
+ * of the reference CLI or NULL. */
+int rt_scene_file_load(const char* json_path, const char* tonemap_name, rt_scene_file** out);
+void rt_scene_file_free(rt_scene_file* f);
+const rt_scene_desc* rt_scene_file_desc(const rt_scene_file* f);
+const rt_camera* rt_scene_file_camera(const rt_scene_file* f);
+const rt_params* rt_scene_file_params(const rt_scene_file* f);
+
+/* Camera::Camera (src/Camera.cpp:9-31). */
+int rt_camera_look_at(rt_camera* out, const double position[3], const double look_at[3],
+                      const double up[3], double fov_deg, double aspect, double aperture,
+                      double focus_dist);
+
+/* RayTracer::writeImageToPPM (RayTracer.cpp:352-367): byte-identical ASCII P3. */
+int rt_write_ppm(const char* path, const double* rgb, int32_t width, int32_t height);
+
+/* BVHNode::BVHNode (src/BVHNode.cpp:7-45) flattened: returns the number of nodes and, when the
+ * out pointers are non-NULL, fills caller arrays of capacity `cap` nodes.  child refs >= 0 are
+ * node indices, refs < 0 encode primitive ~ref.  Host only; used by rt_upload_scene and tests.
+ *   node_box  [cap][6]  min xyz, max xyz
+ *   node_left / node_right [cap]; a leaf (span 1) has left = ~prim and right = INT32_MIN. */
+int rt_build_bvh(const rt_scene_desc* scene, int32_t cap, double* node_box, int32_t* node_left,
+                 int32_t* node_right);
+
+/* ---- device ------------------------------------------------------------------------------ */
+int rt_device_count(void);
+int rt_create(rt_context** out, int device);
+void rt_destroy(rt_context* ctx);
+
+/* Scene::addObject / addLight / buildBVH (Scene.cpp:15-22, 41-42): copies everything. */
+int rt_upload_scene(rt_context* ctx, const rt_scene_desc* scene);
+int rt_set_camera(rt_context* ctx, const rt_camera* cam);
+int rt_set_params(rt_context* ctx, const rt_params* p);
+
+/* Number of rows / doubles this context's partition produces (after rt_set_params). */
+int64_t rt_local_rows(const rt_context* ctx);
+
+/* RayTracer::render / renderPathTrace up to, not including, writeImageToPPM
+ * (RayTracer.cpp:206-246, 254-328).  Blocking.  rgb: host, 3*W*local_rows doubles, final
+ * colours in [0,1].  hit_id: host, W*local_rows int32 primary-hit primitive IDs, or NULL. */
+int rt_render(rt_context* ctx, double* rgb, int32_t* hit_id);
+
+/* Same, asynchronous on `stream` (a hipStream_t, NULL = default stream) into DEVICE buffers
+ * the caller owns (e.g. torch tensors that then feed an RCCL collective). */
+int rt_render_device(rt_context* ctx, void* stream, double* rgb_dev, int32_t* hit_id_dev);
+
+/* Path trace split across GPUs by sample range: writes the un-normalised radiance SUM of this
+ * context's strata (RayTracer.cpp:270-285) to accum_dev (3*W*local_rows doubles), no
+ * division, tone map, exposure or gamma: those are non-linear and come after the reduction. */
+int rt_pathtrace_accumulate_device(rt_context* ctx, void* stream, double* accum_dev);
+
+/* RayTracer.cpp:301-315 (path trace) on n_pixels pixels of a device buffer in place:
+ * / pixelSamples, tone map, * exposure, pow(1/2.2), clamp. */
+int rt_pathtrace_resolve_device(rt_context* ctx, void* stream, double* accum_dev,
+                                int64_t n_pixels);
+
+/* Blocks until the last render on this context finished, then fills stats. */
+int rt_get_stats(rt_context* ctx, rt_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACER_AMD_H */

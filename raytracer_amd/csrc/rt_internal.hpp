@@ -1,0 +1,43 @@
+// rt_internal.hpp -- declarations shared by the host ingest (host_scene.cpp) and the device
+// side (render_hip.hip) of libraytracer_amd.so.  Not part of the C-ABI.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "raytracer_amd.h"
+
+namespace rt {
+
+// thread-local message behind rt_last_error()
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Flattened BVHNode tree (src/BVHNode.cpp:7-45) in DFS pre-order.  Because the reference visits
+// both children of every node it enters, in a fixed left-then-right order, the traversal is a
+// fixed walk over this array: at node i go to i+1 when the box is hit and to skip[i] when it is
+// missed (for a leaf skip[i] == i+1).  prim0/prim1 are the primitives tested at the node:
+//   span 1 leaf  -> prim0 = object, prim1 = -1
+//   span 2 node  -> prim0 = left,   prim1 = right   (no boxes of their own, BVHNode.cpp:21-24)
+//   span >= 3    -> prim0 = prim1 = -1
+struct FlatBVH {
+    std::vector<double> box;     // [n][6] min xyz, max xyz
+    std::vector<int32_t> skip;   // [n]
+    std::vector<int32_t> prim0;  // [n] primitive ID or -1
+    std::vector<int32_t> prim1;  // [n]
+    std::vector<int32_t> right;  // [n] index of the right child node (span >= 3) or -1
+    int size() const { return (int)skip.size(); }
+};
+
+// Builds the tree exactly as the reference constructor does (same axis rule, same std::sort on
+// the same comparison sequence, same span/2 split).
+void build_flat_bvh(const rt_scene_desc* scene, FlatBVH& out);
+
+// Per-primitive AABBs as the reference's getBoundingBox() returns them, including the
+// cylinder box that assumes a +Y axis (src/Cylinder.cpp:131-137).
+void prim_bounds(const rt_scene_desc* scene, int prim, double box[6]);
+
+// Triangle::Triangle normal (src/Triangle.cpp:7-12).
+void triangle_normal(const double* v0, const double* v1, const double* v2, double n[3]);
+
+}  // namespace rt
