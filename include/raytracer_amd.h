@@ -172,6 +172,10 @@ int rt_api_version(void);
  * of the reference CLI or NULL. */
 int rt_scene_file_load(const char* json_path, const char* tonemap_name, rt_scene_file** out);
 void rt_scene_file_free(rt_scene_file* f);
+/* Same effect as editing camera.width / camera.height in the JSON and loading again: the image
+ * size changes and the camera is rebuilt with the new aspect ratio (RayTracer.cpp:838-840).
+ * The shipped scenes are all 1200x800; the 1080p / 4K configurations use this. */
+int rt_scene_file_resize(rt_scene_file* f, int32_t width, int32_t height);
 const rt_scene_desc* rt_scene_file_desc(const rt_scene_file* f);
 const rt_camera* rt_scene_file_camera(const rt_scene_file* f);
 const rt_params* rt_scene_file_params(const rt_scene_file* f);
@@ -226,6 +230,18 @@ int rt_pathtrace_resolve_device(rt_context* ctx, void* stream, double* accum_dev
 
 /* Blocks until the last render on this context finished, then fills stats. */
 int rt_get_stats(rt_context* ctx, rt_stats* out);
+
+/* ---- diagnostics ---------------------------------------------------------------------------
+ * No counterpart in the reference: per-function hooks so that the parity tests can drive
+ * Scene::intersect (src/Scene.cpp:63-81) and the device math library on chosen inputs. */
+/* Closest hit of n rays given as host arrays [n][3]; directions are normalized as the Ray
+ * constructor does (src/Ray.cpp:5-6).  t_out = t or -1, prim_out = primitive ID or -1,
+ * normal_out = HitRecord::normal. */
+int rt_debug_trace_rays(rt_context* ctx, int64_t n, const double* origins, const double* dirs,
+                        double* t_out, int32_t* prim_out, double* normal_out);
+/* out[k] = op(a[k], b[k]) evaluated on the device: 0 a/b, 1 sqrt(a), 2 pow(a,b), 3 atan2(a,b),
+ * 4 acos(a), 5 cos(a), 6 sin(a), 7 RNG uniform(seed 0; pixel a, sample b, node 1, dim 0). */
+int rt_debug_math(rt_context* ctx, int op, int64_t n, const double* a, const double* b, double* out);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,7 @@ SYMBOLS = {
     "rt_api_version": (C.c_int, []),
     "rt_scene_file_load": (C.c_int, [C.c_char_p, C.c_char_p, _P(C.c_void_p)]),
     "rt_scene_file_free": (None, [C.c_void_p]),
+    "rt_scene_file_resize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rt_scene_file_desc": (_P(SceneDesc), [C.c_void_p]),
     "rt_scene_file_camera": (_P(Camera), [C.c_void_p]),
     "rt_scene_file_params": (_P(Params), [C.c_void_p]),
@@ -107,6 +108,8 @@ SYMBOLS = {
     "rt_pathtrace_accumulate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_pathtrace_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "rt_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
+    "rt_debug_trace_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_debug_math": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,191 @@
+// device_math.hpp -- fp64 vector arithmetic and primitive tests for gfx950, written so that every
+// result has the bits the reference's x86-64 build produces: same operation order as
+// src/Vector3.cpp, true IEEE divisions and square roots, no FMA contraction (the translation
+// unit is compiled with -ffp-contract=off), explicit compares instead of min/max intrinsics so
+// NaN cases fall the way the reference's do.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rtd {
+
+struct D3 {
+    double x, y, z;
+};
+RT_DEV D3 mk(double x, double y, double z) { return D3{x, y, z}; }
+RT_DEV D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV D3 operator*(D3 a, D3 b) { return D3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_DEV D3 operator/(D3 a, D3 b) { return D3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+RT_DEV D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+RT_DEV D3 operator/(D3 a, double s) { return D3{a.x / s, a.y / s, a.z / s}; }
+RT_DEV D3 operator+(D3 a, double s) { return D3{a.x + s, a.y + s, a.z + s}; }
+RT_DEV D3 operator-(D3 a, double s) { return D3{a.x - s, a.y - s, a.z - s}; }
+RT_DEV D3 operator-(D3 a) { return D3{-a.x, -a.y, -a.z}; }
+RT_DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // Vector3.cpp:48-50
+RT_DEV D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT_DEV double length(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // Vector3.cpp:72-75
+RT_DEV D3 normalize(D3 a) {                                                       // Vector3.cpp:78-81
+    double len = length(a);
+    return D3{a.x / len, a.y / len, a.z / len};
+}
+RT_DEV D3 ld3(const double* p) { return D3{p[0], p[1], p[2]}; }
+
+// std::max / std::min / std::clamp with the libstdc++ argument order (NaN handling)
+RT_DEV double std_max(double a, double b) { return (a < b) ? b : a; }
+RT_DEV double std_min(double a, double b) { return (b < a) ? b : a; }
+RT_DEV double std_clamp(double v, double lo, double hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
+
+// BoundingBox::intersect (src/BoundingBox.cpp:24-62); b = min xyz, max xyz.
+RT_DEV bool box_hit(const double* b, D3 o, D3 d) {
+    double tmin = (b[0] - o.x) / d.x;
+    double tmax = (b[3] - o.x) / d.x;
+    if (tmin > tmax) { double s = tmin; tmin = tmax; tmax = s; }
+    double tymin = (b[1] - o.y) / d.y;
+    double tymax = (b[4] - o.y) / d.y;
+    if (tymin > tymax) { double s = tymin; tymin = tymax; tymax = s; }
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    double tzmin = (b[2] - o.z) / d.z;
+    double tzmax = (b[5] - o.z) / d.z;
+    if (tzmin > tzmax) { double s = tzmin; tzmin = tzmax; tzmax = s; }
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    if (tzmax < tmax) tmax = tzmax;
+    return tmax > 0;
+}
+
+// Sphere::intersect (src/Sphere.cpp:14-36), t only; s = cx cy cz r.
+RT_DEV bool sphere_t(const double* s, D3 o, D3 d, double& t_out) {
+    D3 oc = o - ld3(s);
+    double a = dot(d, d);
+    double b = 2.0 * dot(oc, d);
+    double c = dot(oc, oc) - s[3] * s[3];
+    double disc = b * b - 4 * a * c;
+    if (disc < 0) return false;
+    double sq = sqrt(disc);
+    double t0 = (-b - sq) / (2.0 * a);
+    double t1 = (-b + sq) / (2.0 * a);
+    double t = t0;
+    if (t < 0) {
+        t = t1;
+        if (t < 0) return false;
+    }
+    t_out = t;
+    return true;
+}
+
+// Triangle::intersect (src/Triangle.cpp:42-80), t only; tr = v0, e1 = v1-v0, e2 = v2-v0, n.
+RT_DEV bool triangle_t(const double* tr, D3 o, D3 d, double& t_out) {
+    const double EPS = 1e-8;
+    D3 v0 = ld3(tr), e1 = ld3(tr + 3), e2 = ld3(tr + 6);
+    D3 h = cross(d, e2);
+    double a = dot(e1, h);
+    if (fabs(a) < EPS) return false;
+    double f = 1.0 / a;
+    D3 s = o - v0;
+    double u = f * dot(s, h);
+    if (u < 0.0 || u > 1.0) return false;
+    D3 q = cross(s, e1);
+    double v = f * dot(d, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    double t = f * dot(e2, q);
+    if (t > EPS) {
+        t_out = t;
+        return true;
+    }
+    return false;
+}
+
+// Cylinder::intersect (src/Cylinder.cpp:13-107); cy = base, axis, r, h.
+// part: 0 side, 1 bottom cap, 2 top cap (selects the normal afterwards).
+RT_DEV bool cylinder_t(const double* cy, D3 o, D3 dir, double& t_out, int& part_out) {
+    D3 base = ld3(cy), axis = ld3(cy + 3);
+    double radius = cy[6], height = cy[7];
+    D3 oc = o - base;
+    D3 d = dir - axis * dot(dir, axis);
+    D3 ocp = oc - axis * dot(oc, axis);
+    double a = dot(d, d);
+    double b = 2.0 * dot(d, ocp);
+    double c = dot(ocp, ocp) - radius * radius;
+    double disc = b * b - 4 * a * c;
+    double t = __builtin_inf();
+    int part = 0;
+    bool hit = false;
+    if (disc >= 0) {
+        double sq = sqrt(disc);
+        double t0 = (-b - sq) / (2 * a);
+        double t1 = (-b + sq) / (2 * a);
+        if (t0 > t1) { double s = t0; t0 = t1; t1 = s; }
+        double y0 = dot(o + dir * t0 - base, axis);
+        if (t0 >= 0 && y0 >= 0 && y0 <= height) {
+            t = t0;
+            hit = true;
+        } else {
+            double y1 = dot(o + dir * t1 - base, axis);
+            if (t1 >= 0 && y1 >= 0 && y1 <= height) {
+                t = t1;
+                hit = true;
+            }
+        }
+    }
+    double tb = dot(base - o, axis) / dot(dir, axis);
+    if (tb >= 0) {
+        D3 p = o + dir * tb;
+        D3 dd = p - base;
+        if (dot(dd, dd) <= radius * radius) {
+            if (tb < t) {
+                t = tb;
+                part = 1;
+                hit = true;
+            }
+        }
+    }
+    D3 top = base + axis * height;
+    double tt = dot(top - o, axis) / dot(dir, axis);
+    if (tt >= 0) {
+        D3 p = o + dir * tt;
+        D3 dd = p - top;
+        if (dot(dd, dd) <= radius * radius) {
+            if (tt < t) {
+                t = tt;
+                part = 2;
+                hit = true;
+            }
+        }
+    }
+    t_out = t;
+    part_out = part;
+    return hit;
+}
+
+// Philox4x32-10 and the uniform stream of DESIGN.md "RNG" (same definition as oracle/oracle.cpp,
+// written independently; both are pinned to the Random123 known-answer vectors).
+RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Rng {
+    uint32_t k0, k1, pixel, sample;
+};
+RT_DEV double rng_u(const Rng& r, uint32_t node, uint32_t dim) {
+    uint32_t o[4];
+    philox4x32_10(r.pixel, r.sample, node, dim >> 1, r.k0, r.k1, o);
+    uint64_t bits = (dim & 1) ? (((uint64_t)o[3] << 32) | o[2]) : (((uint64_t)o[1] << 32) | o[0]);
+    return (double)(bits >> 11) * 0x1.0p-53;
+}
+
+}  // namespace rtd

@@ -178,6 +178,8 @@ struct rt_scene_file {
     rt_scene_desc desc;
     rt_camera camera;
     rt_params params;
+    // parseCamera inputs, kept so that rt_scene_file_resize can rebuild the camera
+    double cam_pos[3], cam_look[3], cam_up[3], cam_fov, cam_aperture, cam_focus;
 };
 
 namespace {
@@ -432,6 +434,12 @@ int rt_scene_file_load(const char* json_path, const char* tonemap_name, rt_scene
         double aperture = cj.value("aperture", 0.0);
         double focus = cj.value("focusDistance", rt::length(rt::sub(rt::h3(look), rt::h3(pos))));
         rt_camera_look_at(&f->camera, pos, look, up, fov, aspect, aperture, focus);
+        std::memcpy(f->cam_pos, pos, sizeof pos);
+        std::memcpy(f->cam_look, look, sizeof look);
+        std::memcpy(f->cam_up, up, sizeof up);
+        f->cam_fov = fov;
+        f->cam_aperture = aperture;
+        f->cam_focus = focus;
 
         Ingest ing;
         ing.f = f.get();
@@ -477,6 +485,15 @@ int rt_scene_file_load(const char* json_path, const char* tonemap_name, rt_scene
 }
 
 void rt_scene_file_free(rt_scene_file* f) { delete f; }
+
+int rt_scene_file_resize(rt_scene_file* f, int32_t width, int32_t height) {
+    if (!f || width < 2 || height < 2) return rt::set_error(RT_ERR_INVALID, "rt_scene_file_resize: bad argument");
+    f->params.width = width;
+    f->params.height = height;
+    double aspect = static_cast<double>(width) / height;  // RayTracer.cpp:840
+    return rt_camera_look_at(&f->camera, f->cam_pos, f->cam_look, f->cam_up, f->cam_fov, aspect, f->cam_aperture,
+                             f->cam_focus);
+}
 const rt_scene_desc* rt_scene_file_desc(const rt_scene_file* f) { return f ? &f->desc : nullptr; }
 const rt_camera* rt_scene_file_camera(const rt_scene_file* f) { return f ? &f->camera : nullptr; }
 const rt_params* rt_scene_file_params(const rt_scene_file* f) { return f ? &f->params : nullptr; }

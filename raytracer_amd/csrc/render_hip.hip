@@ -1,0 +1,1657 @@
+// render_hip.hip -- the MI355X (gfx950) render loop behind include/raytracer_amd.h.
+//
+// Replaces RayTracer::render / renderPathTrace and everything below them
+// (/root/reference/src/RayTracer.cpp:206-350, 373-812; Scene.cpp:63-81; BVHNode.cpp:47-81;
+// BoundingBox.cpp:24-62; Sphere/Triangle/Cylinder::intersect; Camera::getRay; AreaLight::sample;
+// Material::getTextureColor; toneMap).
+//
+// Design (DESIGN.md has the long form):
+//   * One persistent kernel per frame.  Every lane of every wave repeats "rounds": trace ONE ray
+//     (primary, shadow, mirror, refraction or diffuse bounce -- all of them funnel through the same
+//     closest-hit walk, as they do through Scene::intersect in the reference), then run a short
+//     continuation that either emits the lane's next ray or finishes the pixel and pulls a new one
+//     from a global ticket counter.  So the SIMD unit of work is a ray, not a pixel: a lane stuck
+//     in an 80-ray glass pixel does not idle its 63 neighbours.
+//   * The recursion of traceRay/computeShadingPhong/traceRayPath is an explicit per-lane frame
+//     stack in HBM, laid out [depth][field][lane] so that a wave's loads and stores coalesce.
+//     Children are evaluated in the reference's order and combined with the reference's
+//     expressions (post-order), so colours differ from the CPU only where pow/cos/sin/atan2/acos
+//     of the device library differ from glibc in the last bits.
+//   * The scene (flattened BVH + type-tagged primitive arrays) is one "image" blob that every
+//     workgroup copies into LDS when it fits (all shipped scenes do: clutter_500 is 48 KB); the
+//     walk then runs out of LDS with per-lane node addresses.  Larger scenes walk the same image
+//     in global memory (L2-resident).
+//   * The BVH walk is stackless: the reference enters both children of every node whose box is
+//     hit, in a fixed order, so the visit sequence is a fixed pre-order walk with skip links.
+//     Ties resolve to the LAST leaf in that order (BVHNode.cpp:64-69); the linear scan keeps the
+//     FIRST object (Scene.cpp:73).
+//
+// Compile with -ffp-contract=off (see device_math.hpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "device_math.hpp"
+#include "rt_internal.hpp"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+using namespace rtd;
+
+// ------------------------------------------------------------------------------------------------
+// Device-side scene description
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kNodeBytes = 64;  // 6 doubles box, int skip, int ref0, int ref1, int pad
+constexpr int kSphereDoubles = 4;
+constexpr int kTriDoubles = 12;
+constexpr int kCylDoubles = 8;
+constexpr int kBlock = 512;          // threads per workgroup
+constexpr int kMaxLdsImage = 150 * 1024;
+constexpr int kNF = 26;              // doubles per frame
+constexpr int kMaxDepthLimit = 64;
+
+// primitive reference = type << 28 | index within the type's array; -1 = none
+__host__ __device__ inline int make_ref(int type, int idx) { return (type << 28) | idx; }
+RT_DEV int ref_type(int ref) { return ref >> 28; }
+RT_DEV int ref_index(int ref) { return ref & 0x0FFFFFFF; }
+
+struct DMaterial {
+    double ks, kd, reflectivity, ior;
+    double diffuse[3];
+    double specular[3];
+    int spec_exp, reflective, refractive, texture;
+};
+struct DLight {
+    int type, pad;
+    double intensity[3], position[3], normal[3], u[3], v[3];
+    double width, height;
+};
+struct DTexture {
+    int width, height;
+    long long offset;  // into the texel byte array
+};
+
+struct SceneView {
+    int n_nodes, n_prims;
+    int off_nodes, off_sph, off_tri, off_cyl;         // byte offsets into the image
+    int off_gid_sph, off_gid_tri, off_gid_cyl;        // int tables: typed index -> primitive ID
+    int off_ref;                                      // int table: primitive ID -> ref (linear scan)
+    int image_bytes;
+    int n_lights;
+    const unsigned char* image;  // global copy of the image
+    const DMaterial* materials;
+    const int* mat_of_gid;
+    const DLight* lights;
+    const DTexture* textures;
+    const unsigned char* texels;
+    double bg[3];
+};
+
+struct RenderArgs {
+    // camera (src/Camera.cpp)
+    double cam_pos[3], cam_ll[3], cam_hor[3], cam_ver[3], cam_u[3], cam_v[3];
+    double lens_radius;
+    double exposure, bias;
+    int W, H;
+    int mode, tonemap, max_depth;
+    int pixel_samples, light_samples, sqrt_spp;
+    int s_begin, s_end;
+    int band_rows, band_rank, band_world;
+    int local_rows;
+    int tiles_x, total_items;
+    unsigned int seed_lo, seed_hi;
+    int accumulate_only;  // path trace: write raw sums
+    // outputs / workspace
+    double* rgb;
+    int* hit_id;
+    double* frames;           // [max_depth+1][kNF][n_threads]
+    long long frame_stride;   // n_threads
+    unsigned int* ticket;
+    unsigned long long* counters;  // rays, box tests, prim tests
+};
+
+// ------------------------------------------------------------------------------------------------
+// Closest hit (Scene::intersect)
+// ------------------------------------------------------------------------------------------------
+struct HitT {
+    double t;
+    int ref;   // primitive ref or -1
+    int part;  // cylinder part
+};
+
+template <typename P>
+RT_DEV bool prim_t(P img, const SceneView& sv, int ref, D3 o, D3 d, double& t, int& part) {
+    int type = ref_type(ref), idx = ref_index(ref);
+    part = 0;
+    if (type == RT_SPHERE) return sphere_t((const double*)(img + sv.off_sph) + idx * kSphereDoubles, o, d, t);
+    if (type == RT_TRIANGLE) return triangle_t((const double*)(img + sv.off_tri) + idx * kTriDoubles, o, d, t);
+    return cylinder_t((const double*)(img + sv.off_cyl) + idx * kCylDoubles, o, d, t, part);
+}
+
+template <typename P>
+RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, unsigned& n_box, unsigned& n_prim) {
+    HitT best;
+    best.ref = -1;
+    best.part = 0;
+    if (sv.n_nodes > 0) {
+        // BVHNode::intersect as a fixed pre-order walk; "right wins unless left.t < right.t"
+        // == the last leaf among the minimal t.
+        best.t = __builtin_inf();
+        int i = 0;
+        while (i < sv.n_nodes) {
+            const double* nb = (const double*)(img + sv.off_nodes + i * kNodeBytes);
+            const int* ni = (const int*)(nb + 6);
+            int skip = ni[0], r0 = ni[1], r1 = ni[2];
+            ++n_box;
+            bool hit = box_hit(nb, o, d);
+            if (hit && r0 >= 0) {
+                double t;
+                int part;
+                ++n_prim;
+                if (prim_t(img, sv, r0, o, d, t, part) && !(best.t < t)) {
+                    best.t = t;
+                    best.ref = r0;
+                    best.part = part;
+                }
+                if (r1 >= 0) {
+                    ++n_prim;
+                    if (prim_t(img, sv, r1, o, d, t, part) && !(best.t < t)) {
+                        best.t = t;
+                        best.ref = r1;
+                        best.part = part;
+                    }
+                }
+            }
+            i = hit ? i + 1 : skip;
+        }
+    } else {
+        // linear scan (Scene.cpp:67-79): strict <, first object wins
+        best.t = 1.7976931348623157e308;  // numeric_limits<double>::max()
+        const int* refs = (const int*)(img + sv.off_ref);
+        for (int k = 0; k < sv.n_prims; ++k) {
+            int r = refs[k];
+            double t;
+            int part;
+            ++n_prim;
+            if (prim_t(img, sv, r, o, d, t, part) && t < best.t) {
+                best.t = t;
+                best.ref = r;
+                best.part = part;
+            }
+        }
+    }
+    return best;
+}
+
+template <typename P>
+RT_DEV int gid_of_ref(P img, const SceneView& sv, int ref) {
+    int type = ref_type(ref), idx = ref_index(ref);
+    int off = type == RT_SPHERE ? sv.off_gid_sph : (type == RT_TRIANGLE ? sv.off_gid_tri : sv.off_gid_cyl);
+    return ((const int*)(img + off))[idx];
+}
+
+// point and normal of the winning primitive, computed from t exactly as the intersect functions
+// fill the HitRecord (Sphere.cpp:38-40, Triangle.cpp:68-70, Cylinder.cpp:44-47/72/87/95-97).
+template <typename P>
+RT_DEV void hit_geometry(P img, const SceneView& sv, const HitT& h, D3 o, D3 d, D3& point, D3& normal) {
+    int type = ref_type(h.ref), idx = ref_index(h.ref);
+    point = o + d * h.t;
+    if (type == RT_SPHERE) {
+        const double* s = (const double*)(img + sv.off_sph) + idx * kSphereDoubles;
+        normal = normalize(point - ld3(s));
+    } else if (type == RT_TRIANGLE) {
+        const double* tr = (const double*)(img + sv.off_tri) + idx * kTriDoubles;
+        normal = ld3(tr + 9);
+    } else {
+        const double* cy = (const double*)(img + sv.off_cyl) + idx * kCylDoubles;
+        D3 base = ld3(cy), axis = ld3(cy + 3);
+        if (h.part == 0) {
+            double y = dot(o + d * h.t - base, axis);
+            normal = normalize(point - base - axis * y);
+        } else if (h.part == 1) {
+            normal = -axis;
+        } else {
+            normal = axis;
+        }
+    }
+}
+
+// getUV of the three classes (Sphere.cpp:50-57, Triangle.cpp:15-39, Cylinder.cpp:109-129)
+template <typename P>
+RT_DEV void prim_uv(P img, const SceneView& sv, int ref, D3 point, double& u, double& v) {
+    int type = ref_type(ref), idx = ref_index(ref);
+    if (type == RT_SPHERE) {
+        const double* s = (const double*)(img + sv.off_sph) + idx * kSphereDoubles;
+        D3 p = normalize(point - ld3(s));
+        double phi = atan2(p.z, p.x);
+        double theta = acos(p.y);
+        u = (phi + M_PI) / (2 * M_PI);
+        v = theta / M_PI;
+    } else if (type == RT_TRIANGLE) {
+        const double* tr = (const double*)(img + sv.off_tri) + idx * kTriDoubles;
+        D3 e1 = ld3(tr + 3), e2 = ld3(tr + 6);
+        D3 pv = point - ld3(tr);
+        double d00 = dot(e1, e1), d01 = dot(e1, e2), d11 = dot(e2, e2);
+        double d20 = dot(pv, e1), d21 = dot(pv, e2);
+        double denom = d00 * d11 - d01 * d01;
+        double vc = (d11 * d20 - d01 * d21) / denom;
+        double wc = (d00 * d21 - d01 * d20) / denom;
+        double uc = 1.0 - vc - wc;
+        u = (uc + vc) / 2.0;
+        v = (vc + wc) / 2.0;
+    } else {
+        const double* cy = (const double*)(img + sv.off_cyl) + idx * kCylDoubles;
+        D3 axis = ld3(cy + 3);
+        D3 p = point - ld3(cy);
+        double y = dot(p, axis);
+        D3 pp = p - axis * y;
+        double theta = atan2(pp.z, pp.x);
+        if (theta < 0) theta += 2 * M_PI;
+        u = theta / (2 * M_PI);
+        v = y / cy[7];
+        v = std_clamp(v, 0.0, 1.0);
+    }
+}
+
+// Material::getTextureColor (src/Material.cpp:69-86)
+RT_DEV D3 texture_color(const SceneView& sv, const DMaterial& m, double u, double v) {
+    if (m.texture < 0) return ld3(m.diffuse);
+    DTexture t = sv.textures[m.texture];
+    if (t.width <= 0 || t.height <= 0) return ld3(m.diffuse);
+    u = u - floor(u);
+    v = v - floor(v);
+    int x = (int)(u * t.width);
+    int y = (int)((1.0 - v) * t.height);
+    x = x < 0 ? 0 : (x > t.width - 1 ? t.width - 1 : x);
+    y = y < 0 ? 0 : (y > t.height - 1 ? t.height - 1 : y);
+    const unsigned char* px = sv.texels + t.offset + ((long long)y * t.width + x) * 3;
+    return mk(px[0] / 255.0, px[1] / 255.0, px[2] / 255.0);
+}
+
+template <typename P>
+RT_DEV D3 surface_colour(P img, const SceneView& sv, const DMaterial& m, int ref, D3 point) {
+    if (m.texture < 0) return ld3(m.diffuse);
+    double u, v;
+    prim_uv(img, sv, ref, point, u, v);
+    return texture_color(sv, m, u, v);
+}
+
+// toneMap (RayTracer.cpp:161-202)
+RT_DEV D3 uncharted2_partial(D3 x) {
+    const double A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    // float arithmetic on the literals as written: C*B, D*E, D*F, E/F are float products
+    const double CB = (double)(0.10f * 0.50f), DE = (double)(0.20f * 0.02f), DF = (double)(0.20f * 0.30f),
+                 EF = (double)(0.02f / 0.30f);
+    (void)C; (void)D; (void)E; (void)F;
+    return ((x * (x * A + CB) + DE) / (x * (x * A + B) + DF)) - EF;
+}
+RT_DEV D3 tone_map(D3 c, int tm) {
+    if (tm == RT_TONEMAP_REINHARD) return c / (c + mk(1, 1, 1));
+    if (tm == RT_TONEMAP_WARD) {
+        c = c / (c + mk(1, 1, 1));
+        return c * (c * (c * 0.4 + 0.4) + 1.219) / (c * (c * 0.3 + 0.5) + 2.219);
+    }
+    if (tm == RT_TONEMAP_UNCHARTED2) {
+        D3 curr = uncharted2_partial(c * (double)2.0f);
+        D3 W = mk((double)11.2f, (double)11.2f, (double)11.2f);
+        D3 white = mk(1.0, 1.0, 1.0) / uncharted2_partial(W);
+        return curr * white;
+    }
+    return c;
+}
+RT_DEV double clamp01(double x) { return std_min(1.0, std_max(0.0, x)); }
+
+// ------------------------------------------------------------------------------------------------
+// Frame stack
+// ------------------------------------------------------------------------------------------------
+// Field map (doubles).  Whitted and path trace share the first nine.
+enum {
+    F_POINT = 0,   // hit point
+    F_NORMAL = 3,  // HitRecord::normal (unflipped)
+    F_DIR = 6,     // direction of the ray that found the hit (Ray::direction)
+    F_A = 9,       // Whitted: local colour          | PT: albedo (after Russian roulette)
+    F_B = 12,      // Whitted: texture/diffuse colour | PT: direct light
+    F_C = 15,      // Whitted: refracted colour       | PT: area-light accumulator
+    F_D = 18,      // Whitted: diffuse accumulator    | PT: reflected colour (glass)
+    F_E = 21,      // Whitted: specular accumulator (3) | PT: F_E fresnel, F_E+1 cosTheta
+    F_I0 = 24,     // two packed ints: primitive ref | RNG node code (PT) / cylinder part
+    F_I1 = 25      // two packed ints: stage | light index << 8 ... , sample index
+};
+
+struct Frames {
+    double* base;
+    long long stride;
+    long long tid;
+    RT_DEV double& at(int depth, int f) const { return base[((long long)depth * kNF + f) * stride + tid]; }
+    RT_DEV void put3(int depth, int f, D3 v) const {
+        at(depth, f) = v.x;
+        at(depth, f + 1) = v.y;
+        at(depth, f + 2) = v.z;
+    }
+    RT_DEV D3 get3(int depth, int f) const { return mk(at(depth, f), at(depth, f + 1), at(depth, f + 2)); }
+    RT_DEV void puti(int depth, int f, int lo, int hi) const {
+        long long v = ((long long)hi << 32) | (unsigned int)lo;
+        at(depth, f) = __longlong_as_double(v);
+    }
+    RT_DEV void geti(int depth, int f, int& lo, int& hi) const {
+        long long v = __double_as_longlong(at(depth, f));
+        lo = (int)(v & 0xFFFFFFFFll);
+        hi = (int)(v >> 32);
+    }
+};
+
+enum { RAY_NONE = 0, RAY_CLOSEST = 1, RAY_SHADOW = 2 };
+
+struct Lane {
+    D3 o, d;       // current ray (d normalized by the Ray constructor rule)
+    int kind;      // RAY_*
+    int depth;     // recursion depth of the frame the current ray belongs to
+    int px, lrow;  // pixel column, local row
+    int sample;    // path trace: current stratum index
+    bool exhausted;
+};
+
+RT_DEV void set_ray(Lane& L, D3 origin, D3 dir, int kind) {  // Ray::Ray normalizes (Ray.cpp:5-6)
+    L.o = origin;
+    L.d = normalize(dir);
+    L.kind = kind;
+}
+
+RT_DEV int global_row(const RenderArgs& A, int lrow) {
+    return ((lrow / A.band_rows) * A.band_world + A.band_rank) * A.band_rows + lrow % A.band_rows;
+}
+
+// Camera::getRay (src/Camera.cpp:33-49)
+RT_DEV void camera_ray(const RenderArgs& A, double s, double t, bool use_lens, const Rng* rng, D3& origin, D3& dir) {
+    D3 offset = mk(0, 0, 0);
+    D3 pos = ld3(A.cam_pos);
+    if (use_lens && A.lens_radius > 0.0) {
+        double x, y;
+        unsigned k = 0;
+        do {  // randomInUnitDisk (include/Camera.h:37-46)
+            x = -1.0 + 2.0 * rng_u(*rng, 0, 2 + 2 * k);
+            y = -1.0 + 2.0 * rng_u(*rng, 0, 2 + 2 * k + 1);
+            ++k;
+        } while (x * x + y * y >= 1.0);
+        D3 rd = mk(x, y, 0) * A.lens_radius;
+        offset = ld3(A.cam_u) * rd.x + ld3(A.cam_v) * rd.y;
+    }
+    D3 image_point = ld3(A.cam_ll) + ld3(A.cam_hor) * s + ld3(A.cam_ver) * t;
+    D3 rdir = image_point - pos - offset;
+    origin = pos + offset;
+    dir = normalize(rdir);  // normalized here and again by the Ray constructor
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whitted continuation (traceRay / computeShadingPhong, RayTracer.cpp:373-393, 694-804)
+// ------------------------------------------------------------------------------------------------
+enum { ST_LIGHTS = 0, ST_REFLECT = 1, ST_REFR_T = 2, ST_REFR_R = 3 };
+
+RT_DEV double schlick(double cosTheta, double ior) {  // fresnelReflectance, RayTracer.cpp:500-504
+    double r0 = (1.0 - ior) / (1.0 + ior);
+    r0 = r0 * r0;
+    return r0 + (1.0 - r0) * pow(1.0 - cosTheta, 5.0);
+}
+
+RT_DEV D3 light_position(const DLight& Lt) {  // only PointLight overrides getPosition (Light.cpp:9-11)
+    return Lt.type == RT_LIGHT_POINT ? ld3(Lt.position) : mk(0, 0, 0);
+}
+
+template <typename P>
+RT_DEV void finish_pixel_whitted(const RenderArgs& A, Lane& L, D3 color) {
+    color = tone_map(color, A.tonemap);
+    color = color * A.exposure;
+    long long idx = ((long long)L.lrow * A.W + L.px) * 3;
+    A.rgb[idx] = clamp01(color.x);
+    A.rgb[idx + 1] = clamp01(color.y);
+    A.rgb[idx + 2] = clamp01(color.z);
+    L.kind = RAY_NONE;
+}
+
+// Runs after the lane's ray has been traced.  Leaves either a new ray in L (kind != NONE) or the
+// pixel written (kind == NONE).
+template <typename P>
+RT_DEV void advance_whitted(P img, const SceneView& sv, const RenderArgs& A, const Frames& F, Lane& L, const HitT& h) {
+    enum { PC_NEXT_LIGHT, PC_AFTER_LIGHTS, PC_AFTER_REFLECT, PC_RETURN };
+    int pc;
+    int depth = L.depth;
+    // live frame
+    D3 point, normal, dir, local, tex, diffuse, specular;
+    int ref = -1, li = 0;
+    D3 V = mk(0, 0, 0);
+    const D3 bg = ld3(sv.bg);
+
+    if (L.kind == RAY_SHADOW) {
+        // back from the shadow ray of light `li` (RayTracer.cpp:721-743)
+        point = F.get3(depth, F_POINT);
+        normal = F.get3(depth, F_NORMAL);
+        dir = F.get3(depth, F_DIR);
+        tex = F.get3(depth, F_B);
+        diffuse = F.get3(depth, F_D);
+        specular = F.get3(depth, F_E);
+        int stage_li, unused;
+        F.geti(depth, F_I0, ref, unused);
+        F.geti(depth, F_I1, stage_li, unused);
+        li = stage_li >> 8;
+        const DLight& Lt = sv.lights[li];
+        D3 lpos = light_position(Lt);
+        bool in_shadow = false;
+        if (h.ref >= 0) {
+            double ldist = length(lpos - point);
+            if (h.t < ldist) in_shadow = true;
+        }
+        if (!in_shadow) {
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            D3 view = -normalize(dir);
+            D3 ldir = normalize(lpos - point);
+            D3 half = normalize(ldir + view);
+            double df = std_max(0.0, dot(normal, ldir));
+            diffuse = diffuse + tex * m.kd * df * ld3(Lt.intensity);
+            double sf = pow(std_max(0.0, dot(normal, half)), (double)m.spec_exp);
+            specular = specular + ld3(m.specular) * m.ks * sf * ld3(Lt.intensity);
+        }
+        ++li;
+        pc = PC_NEXT_LIGHT;
+    } else {
+        // back from a closest-hit ray at `depth` (traceRay, RayTracer.cpp:379-392)
+        if (depth == 0 && A.hit_id) A.hit_id[(long long)L.lrow * A.W + L.px] = h.ref >= 0 ? gid_of_ref(img, sv, h.ref) : -1;
+        if (h.ref < 0) {
+            V = (A.mode == RT_MODE_BINARY) ? mk(0, 0, 0) : bg;
+            pc = PC_RETURN;
+        } else if (A.mode == RT_MODE_BINARY) {
+            V = mk(1.0, 0.0, 0.0);
+            pc = PC_RETURN;
+        } else {
+            ref = h.ref;
+            dir = L.d;
+            hit_geometry(img, sv, h, L.o, L.d, point, normal);
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            tex = surface_colour(img, sv, m, ref, point);
+            diffuse = mk(0, 0, 0);
+            specular = mk(0, 0, 0);
+            li = 0;
+            pc = PC_NEXT_LIGHT;
+        }
+    }
+
+    for (;;) {
+        if (pc == PC_NEXT_LIGHT) {
+            if (li < sv.n_lights) {
+                const DLight& Lt = sv.lights[li];
+                D3 ldir = normalize(light_position(Lt) - point);
+                F.put3(depth, F_POINT, point);
+                F.put3(depth, F_NORMAL, normal);
+                F.put3(depth, F_DIR, dir);
+                F.put3(depth, F_B, tex);
+                F.put3(depth, F_D, diffuse);
+                F.put3(depth, F_E, specular);
+                F.puti(depth, F_I0, ref, 0);
+                F.puti(depth, F_I1, ST_LIGHTS | (li << 8), 0);
+                L.depth = depth;
+                set_ray(L, point + normal * A.bias, ldir, RAY_SHADOW);
+                return;
+            }
+            local = tex * 0.25 + diffuse + specular;  // ambient + diffuse + specular (:705, :746)
+            pc = PC_AFTER_LIGHTS;
+        } else if (pc == PC_AFTER_LIGHTS) {
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            pc = PC_AFTER_REFLECT;
+            if (m.reflective) {  // :749-760
+                D3 n = normal;
+                if (dot(dir, n) > 0.0) n = -n;
+                D3 rdir = dir - n * 2.0 * dot(dir, n);
+                if (depth + 1 >= A.max_depth) {
+                    local = local * (1 - m.reflectivity) + bg * m.reflectivity;
+                } else {
+                    F.put3(depth, F_POINT, point);
+                    F.put3(depth, F_NORMAL, normal);
+                    F.put3(depth, F_DIR, dir);
+                    F.put3(depth, F_A, local);
+                    F.puti(depth, F_I0, ref, 0);
+                    F.puti(depth, F_I1, ST_REFLECT, 0);
+                    L.depth = depth + 1;
+                    set_ray(L, point + n * A.bias, rdir, RAY_CLOSEST);
+                    return;
+                }
+            }
+        } else if (pc == PC_AFTER_REFLECT) {
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            V = local;
+            pc = PC_RETURN;
+            if (m.refractive && depth < A.max_depth) {  // :764-800
+                double n1 = 1.0, n2 = m.ior;
+                D3 n = normal;
+                if (dot(dir, n) > 0.0) {
+                    n = -n;
+                    double s = n1; n1 = n2; n2 = s;
+                }
+                double eta = n1 / n2;
+                double cosI = -dot(n, dir);
+                double sinT2 = eta * eta * (1.0 - cosI * cosI);
+                if (sinT2 <= 1.0) {
+                    double cosT = sqrt(1.0 - sinT2);
+                    D3 tdir = normalize(dir * eta + n * (eta * cosI - cosT));
+                    double R = schlick(cosI, n2);
+                    if (depth + 1 >= A.max_depth) {
+                        V = bg * R + bg * (1.0 - R);
+                    } else {
+                        F.put3(depth, F_POINT, point);
+                        F.put3(depth, F_NORMAL, normal);
+                        F.put3(depth, F_DIR, dir);
+                        F.at(depth, F_E) = R;
+                        F.puti(depth, F_I0, ref, 0);
+                        F.puti(depth, F_I1, ST_REFR_T, 0);
+                        L.depth = depth + 1;
+                        set_ray(L, point - n * A.bias, tdir, RAY_CLOSEST);
+                        return;
+                    }
+                }
+            }
+        } else {  // PC_RETURN: V is the value of traceRay at `depth`
+            if (depth == 0) {
+                finish_pixel_whitted<P>(A, L, V);
+                return;
+            }
+            --depth;
+            int stage, unused;
+            F.geti(depth, F_I1, stage, unused);
+            F.geti(depth, F_I0, ref, unused);
+            point = F.get3(depth, F_POINT);
+            normal = F.get3(depth, F_NORMAL);
+            dir = F.get3(depth, F_DIR);
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            if (stage == ST_REFLECT) {
+                local = F.get3(depth, F_A);
+                local = local * (1 - m.reflectivity) + V * m.reflectivity;
+                pc = PC_AFTER_REFLECT;
+            } else if (stage == ST_REFR_T) {
+                // refracted colour is in; now the reflected ray (:792-795)
+                D3 n = normal;
+                if (dot(dir, n) > 0.0) n = -n;
+                D3 rdir = dir - n * 2.0 * dot(dir, n);
+                F.put3(depth, F_C, V);
+                F.puti(depth, F_I1, ST_REFR_R, 0);
+                L.depth = depth + 1;
+                set_ray(L, point + n * A.bias, rdir, RAY_CLOSEST);
+                return;
+            } else {  // ST_REFR_R
+                double R = F.at(depth, F_E);
+                D3 tc = F.get3(depth, F_C);
+                V = V * R + tc * (1.0 - R);
+                pc = PC_RETURN;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Path-trace continuation (traceRayPath / estimateDirectLight, RayTracer.cpp:506-689)
+// ------------------------------------------------------------------------------------------------
+enum { PT_LIGHTS = 0, PT_MIRROR = 1, PT_GLASS_R = 2, PT_GLASS_T = 3, PT_DIFFUSE = 4 };
+enum { DIM_RR = 0, DIM_HEMI_1 = 1, DIM_HEMI_2 = 2, DIM_LIGHT0 = 4 };
+
+RT_DEV D3 reflect_v(D3 v, D3 n) { return v - n * 2.0 * dot(v, n); }  // RayTracer.cpp:477-481
+RT_DEV D3 refract_v(D3 I, D3 N, double eta_t, double eta_i) {        // RayTracer.cpp:430-448
+    double cosi = -std_max(-1.0, std_min(1.0, dot(I, N)));
+    if (cosi < 0) {  // one level of the reference's recursion: -N, swapped indices
+        N = -N;
+        double s = eta_t; eta_t = eta_i; eta_i = s;
+        cosi = -std_max(-1.0, std_min(1.0, dot(I, N)));
+        // a second flip cannot happen for finite inputs (cosi would have to be < 0 both ways)
+    }
+    double eta = eta_i / eta_t;
+    double k = 1 - eta * eta * (1 - cosi * cosi);
+    if (k < 0) return mk(0, 0, 0);
+    return I * eta + N * (eta * cosi - sqrt(k));
+}
+RT_DEV double fresnel_f(D3 I, D3 N, double eta_t, double eta_i) {  // RayTracer.cpp:453-472
+    double cosi = std_clamp(dot(I, N), -1.0, 1.0);
+    double etai = eta_i, etat = eta_t;
+    if (cosi > 0) { double s = etai; etai = etat; etat = s; }
+    double sint = etai / etat * sqrt(std_max(0.0, 1 - cosi * cosi));
+    if (sint >= 1) return 1.0;
+    double cost = sqrt(std_max(0.0, 1 - sint * sint));
+    cosi = fabs(cosi);
+    double Rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    double Rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    return (Rs * Rs + Rp * Rp) / 2.0;
+}
+RT_DEV D3 hemisphere(D3 n, double r1, double r2) {  // randomInHemisphere, RayTracer.cpp:398-424
+    double sinTheta = sqrt(1 - r1 * r1);
+    double phi = 2 * M_PI * r2;
+    double x = cos(phi) * sinTheta;
+    double y = r1;
+    double z = sin(phi) * sinTheta;
+    D3 tangent;
+    if (fabs(n.x) > fabs(n.y)) tangent = normalize(mk(-n.z, 0, n.x));
+    else tangent = normalize(mk(0, n.z, -n.y));
+    D3 bitangent = cross(n, tangent);
+    D3 dir = tangent * x + n * y + bitangent * z;
+    return normalize(dir);
+}
+
+// AreaLight::sample (src/AreaLight.cpp:3-20) for sample `si` of light `li` at RNG node `node`
+RT_DEV void area_sample(const RenderArgs& A, const DLight& Lt, const Rng& rng, unsigned node, int li, int si, D3 point,
+                        D3& ldir, double& distance, double& pdf) {
+    unsigned dim = DIM_LIGHT0 + 2u * (unsigned)(li * A.light_samples + si);
+    double su = (rng_u(rng, node, dim) - 0.5) * Lt.width;
+    double sv = (rng_u(rng, node, dim + 1) - 0.5) * Lt.height;
+    D3 sp = ld3(Lt.position) + ld3(Lt.u) * su + ld3(Lt.v) * sv;
+    ldir = sp - point;
+    distance = length(ldir);
+    ldir = ldir / distance;
+    double area = Lt.width * Lt.height;
+    double cosine = std_max(0.0, dot(ld3(Lt.normal), -ldir));
+    pdf = (distance * distance) / (area * cosine);
+}
+
+template <typename P>
+RT_DEV D3 brdf_eval(P img, const SceneView& sv, const DMaterial& m, int ref, D3 point, D3 normal, D3 ldir, D3 view) {
+    D3 dbrdf = (ld3(m.diffuse) * m.kd) / M_PI;
+    if (m.texture >= 0) {
+        double u, v;
+        prim_uv(img, sv, ref, point, u, v);
+        dbrdf = texture_color(sv, m, u, v) * m.kd / M_PI;
+    }
+    D3 half = normalize(ldir + view);
+    double ndoth = std_max(0.0, dot(normal, half));
+    double sf = pow(ndoth, (double)m.spec_exp);
+    D3 sbrdf = ld3(m.specular) * m.ks * ((m.spec_exp + 2.0) / (2.0 * M_PI)) * sf;
+    return dbrdf + sbrdf;
+}
+
+// Starts stratum L.sample of the lane's pixel (RayTracer.cpp:270-283) or finishes the pixel.
+RT_DEV void pt_next_sample(const RenderArgs& A, const Frames& F, Lane& L, Rng& rng) {
+    const int pix_slot = A.max_depth;  // frame level used for the per-pixel colour sum
+    if (L.sample >= A.s_end) {
+        D3 color = F.get3(pix_slot, 0);
+        long long idx = ((long long)L.lrow * A.W + L.px) * 3;
+        if (A.accumulate_only) {
+            A.rgb[idx] = color.x;
+            A.rgb[idx + 1] = color.y;
+            A.rgb[idx + 2] = color.z;
+        } else {  // RayTracer.cpp:301-315
+            color = color / (double)A.pixel_samples;
+            color = tone_map(color, A.tonemap);
+            color = color * A.exposure;
+            color.x = pow(color.x, 1.0 / 2.2);
+            color.y = pow(color.y, 1.0 / 2.2);
+            color.z = pow(color.z, 1.0 / 2.2);
+            A.rgb[idx] = clamp01(color.x);
+            A.rgb[idx + 1] = clamp01(color.y);
+            A.rgb[idx + 2] = clamp01(color.z);
+        }
+        L.kind = RAY_NONE;
+        return;
+    }
+    int s = L.sample;
+    int sx = s % A.sqrt_spp, sy = s / A.sqrt_spp;
+    rng.sample = (unsigned)s;
+    int j = global_row(A, L.lrow);
+    double r1 = (sx + rng_u(rng, 0, 0)) / A.sqrt_spp;
+    double r2 = (sy + rng_u(rng, 0, 1)) / A.sqrt_spp;
+    double u = 1.0 - ((double)L.px + r1) / (A.W - 1);
+    double v = ((double)j + r2) / (A.H - 1);
+    D3 origin, dir;
+    camera_ray(A, u, v, true, &rng, origin, dir);
+    L.depth = 0;
+    set_ray(L, origin, dir, RAY_CLOSEST);
+}
+
+template <typename P>
+RT_DEV void advance_path(P img, const SceneView& sv, const RenderArgs& A, const Frames& F, Lane& L, Rng& rng,
+                         const HitT& h) {
+    enum { PC_LIGHT_LOOP, PC_MATERIAL, PC_RETURN };
+    int pc;
+    int depth = L.depth;
+    D3 point, normal, dir, albedo, direct, acc;
+    int ref = -1, li = 0, si = 0;
+    unsigned node = 1;
+    D3 V = mk(0, 0, 0);
+    const D3 bg = ld3(sv.bg);
+
+    if (L.kind == RAY_SHADOW) {
+        point = F.get3(depth, F_POINT);
+        normal = F.get3(depth, F_NORMAL);
+        dir = F.get3(depth, F_DIR);
+        albedo = F.get3(depth, F_A);
+        direct = F.get3(depth, F_B);
+        acc = F.get3(depth, F_C);
+        int inode, packed;
+        F.geti(depth, F_I0, ref, inode);
+        node = (unsigned)inode;
+        F.geti(depth, F_I1, packed, si);
+        li = packed >> 8;
+        const DLight& Lt = sv.lights[li];
+        const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+        D3 view = -normalize(dir);
+        if (Lt.type == RT_LIGHT_POINT) {  // RayTracer.cpp:602-637
+            D3 lpos = ld3(Lt.position);
+            D3 ldir = normalize(lpos - point);
+            double distance = length(lpos - point);
+            bool shadowed = (h.ref >= 0) && (h.t < distance);
+            if (!shadowed) {
+                double ndotl = std_max(0.0, dot(normal, ldir));
+                D3 brdf = brdf_eval(img, sv, m, ref, point, normal, ldir, view);
+                direct = direct + brdf * ld3(Lt.intensity) * ndotl;
+            }
+            ++li;
+            si = 0;
+        } else {  // RayTracer.cpp:643-684
+            D3 ldir;
+            double distance, pdf;
+            area_sample(A, Lt, rng, node, li, si, point, ldir, distance, pdf);
+            bool shadowed = (h.ref >= 0) && (h.t < distance);
+            if (!shadowed) {
+                double ndotl = std_max(0.0, dot(normal, ldir));
+                double ndotl_light = std_max(0.0, dot(ld3(Lt.normal), -ldir));
+                if (ndotl > 0 && ndotl_light > 0) {
+                    D3 brdf = brdf_eval(img, sv, m, ref, point, normal, ldir, view);
+                    acc = acc + brdf * ld3(Lt.intensity) * ndotl * ndotl_light / pdf;
+                }
+            }
+            ++si;
+            if (si >= A.light_samples) {
+                direct = direct + acc / (double)A.light_samples;
+                acc = mk(0, 0, 0);
+                si = 0;
+                ++li;
+            }
+        }
+        pc = PC_LIGHT_LOOP;
+    } else {
+        // back from a closest-hit ray: traceRayPath body up to the direct light (:511-539)
+        if (depth == 0) node = 1;
+        else {
+            // the node code of this hit was stored by the parent when it launched the ray
+            int lo, hi;
+            F.geti(depth, F_I0, lo, hi);
+            node = (unsigned)hi;
+        }
+        if (h.ref < 0) {
+            V = bg;
+            pc = PC_RETURN;
+        } else {
+            ref = h.ref;
+            dir = L.d;
+            hit_geometry(img, sv, h, L.o, L.d, point, normal);
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            albedo = surface_colour(img, sv, m, ref, point);
+            pc = PC_LIGHT_LOOP;
+            if (depth > 3) {  // Russian roulette (:530-536)
+                double maxR = std_max(albedo.x, std_max(albedo.y, albedo.z));
+                if (rng_u(rng, node, DIM_RR) > maxR) {
+                    V = mk(0, 0, 0);
+                    pc = PC_RETURN;
+                } else {
+                    albedo = albedo / maxR;
+                }
+            }
+            direct = mk(0, 0, 0);
+            acc = mk(0, 0, 0);
+            li = 0;
+            si = 0;
+        }
+    }
+
+    for (;;) {
+        if (pc == PC_LIGHT_LOOP) {
+            // skip area lights with no samples (the reference's loop body never runs; 0/0 follows)
+            if (li < sv.n_lights && sv.lights[li].type == RT_LIGHT_AREA && A.light_samples <= 0) {
+                direct = direct + acc / (double)A.light_samples;
+                ++li;
+                continue;
+            }
+            if (li < sv.n_lights) {
+                const DLight& Lt = sv.lights[li];
+                D3 ldir;
+                if (Lt.type == RT_LIGHT_POINT) {
+                    ldir = normalize(ld3(Lt.position) - point);
+                } else {
+                    double distance, pdf;
+                    area_sample(A, Lt, rng, node, li, si, point, ldir, distance, pdf);
+                }
+                F.put3(depth, F_POINT, point);
+                F.put3(depth, F_NORMAL, normal);
+                F.put3(depth, F_DIR, dir);
+                F.put3(depth, F_A, albedo);
+                F.put3(depth, F_B, direct);
+                F.put3(depth, F_C, acc);
+                F.puti(depth, F_I0, ref, (int)node);
+                F.puti(depth, F_I1, PT_LIGHTS | (li << 8), si);
+                L.depth = depth;
+                set_ray(L, point + normal * A.bias, ldir, RAY_SHADOW);
+                return;
+            }
+            pc = PC_MATERIAL;
+        } else if (pc == PC_MATERIAL) {
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            D3 nf = normal;
+            if (dot(dir, nf) > 0) nf = -nf;
+            bool child_possible = depth + 1 < A.max_depth;  // else traceRayPath returns 0 with no ray
+            // common part of the frame
+            F.put3(depth, F_POINT, point);
+            F.put3(depth, F_NORMAL, normal);
+            F.put3(depth, F_DIR, dir);
+            F.put3(depth, F_A, albedo);
+            F.put3(depth, F_B, direct);
+            if (m.reflective) {  // :543-549
+                D3 rdir = normalize(reflect_v(normalize(dir), nf));
+                if (!child_possible) {
+                    V = direct + mk(0, 0, 0) * m.reflectivity;
+                    pc = PC_RETURN;
+                    continue;
+                }
+                F.puti(depth, F_I0, ref, (int)node);
+                F.puti(depth, F_I1, PT_MIRROR, 0);
+                F.puti(depth + 1, F_I0, 0, (int)(2 * node));
+                L.depth = depth + 1;
+                set_ray(L, point + nf * A.bias, rdir, RAY_CLOSEST);
+                return;
+            } else if (m.refractive) {  // :551-584
+                D3 n = normal;
+                double eta_i = 1.0, eta_t = m.ior;
+                D3 incident = normalize(dir);
+                bool entering = dot(incident, n) < 0;
+                if (!entering) {
+                    double s = eta_i; eta_i = eta_t; eta_t = s;
+                    n = -n;
+                }
+                D3 bias = n * A.bias;
+                D3 rdir = normalize(reflect_v(incident, n));
+                if (!child_possible) {
+                    // both children return 0 without tracing
+                    double Fr = fresnel_f(incident, n, eta_t, eta_i);
+                    D3 tdir = normalize(refract_v(incident, n, eta_t, eta_i));
+                    D3 zero = mk(0, 0, 0);
+                    D3 indirect = (length(tdir) > 0.0) ? (zero * Fr + zero * (1.0 - Fr)) : zero;
+                    V = direct + indirect;
+                    pc = PC_RETURN;
+                    continue;
+                }
+                F.puti(depth, F_I0, ref, (int)node);
+                F.puti(depth, F_I1, PT_GLASS_R, 0);
+                F.puti(depth + 1, F_I0, 0, (int)(2 * node));
+                L.depth = depth + 1;
+                set_ray(L, point + bias, rdir, RAY_CLOSEST);
+                return;
+            } else {  // diffuse, :585-592
+                D3 nd = hemisphere(nf, rng_u(rng, node, DIM_HEMI_1), rng_u(rng, node, DIM_HEMI_2));
+                double cosTheta = std_max(0.0, dot(nd, nf));
+                if (!child_possible) {
+                    V = direct + mk(0, 0, 0) * (albedo / M_PI) * cosTheta;
+                    pc = PC_RETURN;
+                    continue;
+                }
+                F.at(depth, F_E + 1) = cosTheta;
+                F.puti(depth, F_I0, ref, (int)node);
+                F.puti(depth, F_I1, PT_DIFFUSE, 0);
+                F.puti(depth + 1, F_I0, 0, (int)(2 * node));
+                L.depth = depth + 1;
+                set_ray(L, point + nf * A.bias, nd, RAY_CLOSEST);
+                return;
+            }
+        } else {  // PC_RETURN: V = traceRayPath at `depth`
+            if (depth == 0) {
+                const int pix_slot = A.max_depth;
+                D3 color = F.get3(pix_slot, 0);
+                color = color + V;
+                F.put3(pix_slot, 0, color);
+                ++L.sample;
+                pt_next_sample(A, F, L, rng);
+                return;
+            }
+            --depth;
+            int stage, unused, inode;
+            F.geti(depth, F_I1, stage, unused);
+            F.geti(depth, F_I0, ref, inode);
+            node = (unsigned)inode;
+            stage &= 0xFF;
+            direct = F.get3(depth, F_B);
+            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            if (stage == PT_MIRROR) {
+                V = direct + V * m.reflectivity;
+            } else if (stage == PT_DIFFUSE) {
+                albedo = F.get3(depth, F_A);
+                double cosTheta = F.at(depth, F_E + 1);
+                V = direct + V * (albedo / M_PI) * cosTheta;
+            } else {
+                point = F.get3(depth, F_POINT);
+                normal = F.get3(depth, F_NORMAL);
+                dir = F.get3(depth, F_DIR);
+                D3 n = normal;
+                double eta_i = 1.0, eta_t = m.ior;
+                D3 incident = normalize(dir);
+                if (!(dot(incident, n) < 0)) {
+                    double s = eta_i; eta_i = eta_t; eta_t = s;
+                    n = -n;
+                }
+                if (stage == PT_GLASS_R) {
+                    // reflected colour is in; refraction next (:571-582)
+                    D3 tdir = normalize(refract_v(incident, n, eta_t, eta_i));
+                    if (length(tdir) > 0.0) {  // false for the NaN of total internal reflection
+                        F.put3(depth, F_D, V);
+                        F.puti(depth, F_I1, PT_GLASS_T, 0);
+                        F.puti(depth + 1, F_I0, 0, (int)(2 * node + 1));
+                        L.depth = depth + 1;
+                        set_ray(L, point - n * A.bias, tdir, RAY_CLOSEST);
+                        return;
+                    }
+                    V = direct + V;
+                } else {  // PT_GLASS_T
+                    double Fr = fresnel_f(incident, n, eta_t, eta_i);
+                    D3 rc = F.get3(depth, F_D);
+                    V = direct + (rc * Fr + V * (1.0 - Fr));
+                }
+            }
+            pc = PC_RETURN;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The persistent kernel
+// ------------------------------------------------------------------------------------------------
+template <bool kLds>
+__global__ void __launch_bounds__(kBlock) render_kernel(SceneView sv, RenderArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
+    const unsigned char* img;
+    if (kLds) {
+        // stage the scene image in LDS, 16 bytes per lane per step
+        const uint4* src = (const uint4*)sv.image;
+        uint4* dst = (uint4*)lds_image;
+        int n16 = sv.image_bytes >> 4;
+        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+        __syncthreads();
+        img = lds_image;
+    } else {
+        img = sv.image;
+    }
+
+    Frames F;
+    F.base = A.frames;
+    F.stride = A.frame_stride;
+    F.tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+
+    Lane L;
+    L.kind = RAY_NONE;
+    L.exhausted = false;
+    L.depth = 0;
+    L.px = L.lrow = 0;
+    L.sample = 0;
+    L.o = L.d = mk(0, 0, 0);
+    Rng rng;
+    rng.k0 = A.seed_lo;
+    rng.k1 = A.seed_hi;
+    rng.pixel = rng.sample = 0;
+    unsigned n_rays = 0, n_box = 0, n_prim = 0;
+
+    for (;;) {
+        // refill: lanes without a ray pull the next pixel ticket (8x8 tiles of the local rows)
+        while (L.kind == RAY_NONE && !L.exhausted) {
+            unsigned k = atomicAdd(A.ticket, 1u);
+            if (k >= (unsigned)A.total_items) {
+                L.exhausted = true;
+                break;
+            }
+            unsigned tile = k >> 6, in = k & 63;
+            int px = (int)(tile % A.tiles_x) * 8 + (int)(in & 7);
+            int lrow = (int)(tile / A.tiles_x) * 8 + (int)(in >> 3);
+            if (px >= A.W || lrow >= A.local_rows) continue;
+            L.px = px;
+            L.lrow = lrow;
+            int j = global_row(A, lrow);
+            if (A.mode == RT_MODE_PATHTRACE) {
+                rng.pixel = (unsigned)((long long)j * A.W + px);
+                F.put3(A.max_depth, 0, mk(0, 0, 0));
+                L.sample = A.s_begin;
+                pt_next_sample(A, F, L, rng);  // may finish the pixel at once when the range is empty
+            } else {  // RayTracer.cpp:217-220
+                double u = 1.0 - ((double)px / (A.W - 1));
+                double v = (double)j / (A.H - 1);
+                D3 origin, dir;
+                camera_ray(A, u, v, false, nullptr, origin, dir);
+                L.depth = 0;
+                set_ray(L, origin, dir, RAY_CLOSEST);
+            }
+        }
+        if (!__any(L.kind != RAY_NONE)) break;  // every lane is out of work and out of tickets
+
+        if (L.kind != RAY_NONE) {
+            ++n_rays;
+            HitT h = closest_hit(img, sv, L.o, L.d, n_box, n_prim);
+            if (A.mode == RT_MODE_PATHTRACE) advance_path(img, sv, A, F, L, rng, h);
+            else advance_whitted(img, sv, A, F, L, h);
+        }
+    }
+
+    // one atomic per wave per counter
+    unsigned long long r = n_rays, b = n_box, p = n_prim;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        b += __shfl_down(b, off);
+        p += __shfl_down(p, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&A.counters[0], r);
+        atomicAdd(&A.counters[1], b);
+        atomicAdd(&A.counters[2], p);
+    }
+}
+
+// RayTracer.cpp:301-315 on a flat buffer
+__global__ void resolve_kernel(double* buf, long long n_pixels, int pixel_samples, int tonemap, double exposure) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_pixels) return;
+    D3 color = mk(buf[k * 3], buf[k * 3 + 1], buf[k * 3 + 2]);
+    color = color / (double)pixel_samples;
+    color = tone_map(color, tonemap);
+    color = color * exposure;
+    color.x = pow(color.x, 1.0 / 2.2);
+    color.y = pow(color.y, 1.0 / 2.2);
+    color.z = pow(color.z, 1.0 / 2.2);
+    buf[k * 3] = clamp01(color.x);
+    buf[k * 3 + 1] = clamp01(color.y);
+    buf[k * 3 + 2] = clamp01(color.z);
+}
+
+// ---- diagnostics kernels (rt_debug_*) ------------------------------------------------------------
+__global__ void debug_trace_kernel(SceneView sv, long long n, const double* origins, const double* dirs, double* t_out,
+                                   int* prim_out, double* normal_out) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const unsigned char* img = sv.image;
+    D3 o = ld3(origins + 3 * k);
+    D3 d = normalize(ld3(dirs + 3 * k));
+    unsigned nb = 0, np = 0;
+    HitT h = closest_hit(img, sv, o, d, nb, np);
+    if (h.ref >= 0) {
+        D3 point, normal;
+        hit_geometry(img, sv, h, o, d, point, normal);
+        t_out[k] = h.t;
+        prim_out[k] = gid_of_ref(img, sv, h.ref);
+        normal_out[3 * k] = normal.x;
+        normal_out[3 * k + 1] = normal.y;
+        normal_out[3 * k + 2] = normal.z;
+    } else {
+        t_out[k] = -1.0;
+        prim_out[k] = -1;
+        normal_out[3 * k] = normal_out[3 * k + 1] = normal_out[3 * k + 2] = 0.0;
+    }
+}
+
+__global__ void debug_math_kernel(int op, long long n, const double* a, const double* b, double* out) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double x = a[k], y = b ? b[k] : 0.0, r;
+    switch (op) {
+        case 0: r = x / y; break;
+        case 1: r = sqrt(x); break;
+        case 2: r = pow(x, y); break;
+        case 3: r = atan2(x, y); break;
+        case 4: r = acos(x); break;
+        case 5: r = cos(x); break;
+        case 6: r = sin(x); break;
+        case 7: {  // uniform(seed = 0; pixel = x, sample = y, node 1, dim 0) for RNG parity
+            Rng g;
+            g.k0 = 0; g.k1 = 0;
+            g.pixel = (unsigned)x;
+            g.sample = (unsigned)y;
+            r = rng_u(g, 1, 0);
+            break;
+        }
+        default: r = 0.0;
+    }
+    out[k] = r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Host side of the device library
+// ------------------------------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return rt::set_error(RT_ERR_DEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct rt_context {
+    int device = 0;
+    int n_cus = 0;
+    bool have_scene = false, have_camera = false, have_params = false;
+    SceneView sv;
+    rt_camera cam;
+    rt_params params;
+    // device allocations
+    unsigned char* d_image = nullptr;
+    DMaterial* d_materials = nullptr;
+    int* d_mat_of_gid = nullptr;
+    DLight* d_lights = nullptr;
+    DTexture* d_textures = nullptr;
+    unsigned char* d_texels = nullptr;
+    double* d_frames = nullptr;
+    size_t frames_bytes = 0;
+    unsigned int* d_ticket = nullptr;
+    unsigned long long* d_counters = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    hipStream_t last_stream = nullptr;
+    double upload_ms = 0.0;
+    int n_bvh_nodes = 0;
+    int scene_in_lds = 0;
+    int sqrt_spp = 0;
+};
+
+namespace {
+
+void free_scene(rt_context* c) {
+    (void)hipFree(c->d_image);
+    (void)hipFree(c->d_materials);
+    (void)hipFree(c->d_mat_of_gid);
+    (void)hipFree(c->d_lights);
+    (void)hipFree(c->d_textures);
+    (void)hipFree(c->d_texels);
+    c->d_image = nullptr;
+    c->d_materials = nullptr;
+    c->d_mat_of_gid = nullptr;
+    c->d_lights = nullptr;
+    c->d_textures = nullptr;
+    c->d_texels = nullptr;
+    c->have_scene = false;
+}
+
+int64_t local_rows_of(const rt_params& p) {
+    int br = p.band_rows > 0 ? p.band_rows : 8;
+    int world = p.band_world > 0 ? p.band_world : 1;
+    int64_t n_bands = (p.height + br - 1) / br;
+    int64_t rows = 0;
+    for (int64_t b = p.band_rank; b < n_bands; b += world) {
+        int64_t r0 = b * br, r1 = std::min<int64_t>(p.height, r0 + br);
+        rows += r1 - r0;
+    }
+    return rows;
+}
+
+int align16(int x) { return (x + 15) & ~15; }
+
+struct H3 {
+    double x, y, z;
+};
+H3 h_normalize(const double* p) {  // Vector3::normalize on the host, same operation order
+    double len = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    return H3{p[0] / len, p[1] / len, p[2] / len};
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_dev, bool accumulate_only) {
+    if (!c->have_scene || !c->have_camera || !c->have_params)
+        return rt::set_error(RT_ERR_STATE, "render: scene, camera and params must be set first");
+    const rt_params& p = c->params;
+    HIP_TRY(hipSetDevice(c->device));
+    RenderArgs A;
+    std::memset(&A, 0, sizeof A);
+    std::memcpy(A.cam_pos, c->cam.position, sizeof A.cam_pos);
+    std::memcpy(A.cam_ll, c->cam.lower_left, sizeof A.cam_ll);
+    std::memcpy(A.cam_hor, c->cam.horizontal, sizeof A.cam_hor);
+    std::memcpy(A.cam_ver, c->cam.vertical, sizeof A.cam_ver);
+    std::memcpy(A.cam_u, c->cam.u, sizeof A.cam_u);
+    std::memcpy(A.cam_v, c->cam.v, sizeof A.cam_v);
+    A.lens_radius = c->cam.lens_radius;
+    A.exposure = p.exposure;
+    A.bias = p.shadow_bias;
+    A.W = p.width;
+    A.H = p.height;
+    A.mode = p.mode;
+    A.tonemap = p.tonemap;
+    A.max_depth = p.max_depth;
+    A.pixel_samples = p.pixel_samples;
+    A.light_samples = p.light_samples;
+    A.sqrt_spp = c->sqrt_spp;
+    A.s_begin = std::max(0, p.sample_begin);
+    A.s_end = p.sample_end > 0 ? std::min(p.sample_end, c->sqrt_spp * c->sqrt_spp) : c->sqrt_spp * c->sqrt_spp;
+    A.band_rows = p.band_rows;
+    A.band_rank = p.band_rank;
+    A.band_world = p.band_world;
+    A.local_rows = (int)local_rows_of(p);
+    A.tiles_x = (p.width + 7) / 8;
+    int tiles_y = (A.local_rows + 7) / 8;
+    long long total = (long long)A.tiles_x * tiles_y * 64;
+    if (total >= 0x7FFFFFFFll) return rt::set_error(RT_ERR_LIMIT, "render: more than 2^31 pixel tickets in one call");
+    A.total_items = (int)total;
+    A.seed_lo = (unsigned)(p.seed & 0xFFFFFFFFull);
+    A.seed_hi = (unsigned)(p.seed >> 32);
+    A.accumulate_only = accumulate_only ? 1 : 0;
+    A.rgb = rgb_dev;
+    A.hit_id = hit_dev;
+    A.ticket = c->d_ticket;
+    A.counters = c->d_counters;
+
+    // persistent grid: as many workgroups as the chip holds at once
+    bool lds = c->sv.image_bytes <= kMaxLdsImage;
+    size_t lds_bytes = lds ? (size_t)c->sv.image_bytes : 0;
+    int per_cu = 0;
+    if (lds)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true>, kBlock, lds_bytes));
+    else
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, kBlock, 0));
+    if (per_cu < 1) per_cu = 1;
+    long long want_blocks = (total + kBlock - 1) / kBlock;
+    int grid = (int)std::min<long long>((long long)per_cu * c->n_cus, std::max<long long>(want_blocks, 1));
+    c->scene_in_lds = lds ? 1 : 0;
+
+    long long n_threads = (long long)grid * kBlock;
+    size_t need = (size_t)(p.max_depth + 1) * kNF * (size_t)n_threads * sizeof(double);
+    if (need > c->frames_bytes) {
+        if (c->d_frames) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(c->d_frames);
+            c->d_frames = nullptr;
+            c->frames_bytes = 0;
+        }
+        HIP_TRY(hipMalloc((void**)&c->d_frames, need));
+        c->frames_bytes = need;
+    }
+    A.frames = c->d_frames;
+    A.frame_stride = n_threads;
+
+    HIP_TRY(hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(c->ev_start, stream));
+    if (lds) {
+        if (lds_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes));
+        hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, c->sv, A);
+    } else {
+        hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, c->sv, A);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_stop, stream));
+    c->timed = true;
+    c->last_stream = stream;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_create(rt_context** out, int device) {
+    if (!out) return rt::set_error(RT_ERR_INVALID, "rt_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return rt::set_error(RT_ERR_DEVICE, "rt_create: no HIP device (%s); this library has no CPU fallback",
+                             e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return rt::set_error(RT_ERR_INVALID, "rt_create: device %d of %d", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return rt::set_error(RT_ERR_DEVICE, "rt_create: device %d is %s; the kernels are built for gfx950 only", device,
+                             prop.gcnArchName);
+    rt_context* c = new rt_context();
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    std::memset(&c->sv, 0, sizeof c->sv);
+    hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
+    hipError_t b = hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long));
+    hipError_t s0 = hipEventCreate(&c->ev_start);
+    hipError_t s1 = hipEventCreate(&c->ev_stop);
+    if (a != hipSuccess || b != hipSuccess || s0 != hipSuccess || s1 != hipSuccess) {
+        rt_destroy(c);
+        return rt::set_error(RT_ERR_DEVICE, "rt_create: device allocation failed");
+    }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_scene(c);
+    (void)hipFree(c->d_frames);
+    (void)hipFree(c->d_ticket);
+    (void)hipFree(c->d_counters);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    delete c;
+}
+
+int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
+    if (!c || !s) return rt::set_error(RT_ERR_INVALID, "rt_upload_scene: null argument");
+    if (s->n_prims < 0 || s->n_prims >= (1 << 28)) return rt::set_error(RT_ERR_LIMIT, "rt_upload_scene: n_prims out of range");
+    for (int i = 0; i < s->n_prims; ++i) {
+        int t = s->prim_type[i], m = s->prim_material[i];
+        if (t < RT_SPHERE || t > RT_CYLINDER) return rt::set_error(RT_ERR_INVALID, "primitive %d: unknown type %d", i, t);
+        if (m < 0 || m >= s->n_materials) return rt::set_error(RT_ERR_INVALID, "primitive %d: material %d of %d", i, m, s->n_materials);
+    }
+    for (int i = 0; i < s->n_materials; ++i) {
+        int t = s->materials[i].texture;
+        if (t >= s->n_textures) return rt::set_error(RT_ERR_INVALID, "material %d: texture %d of %d", i, t, s->n_textures);
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    free_scene(c);
+
+    // ---- flatten: per-type arrays in primitive order ------------------------------------------
+    std::vector<double> sph, tri, cyl;
+    std::vector<int> gid_sph, gid_tri, gid_cyl, ref_of_gid(s->n_prims);
+    for (int i = 0; i < s->n_prims; ++i) {
+        const double* g = s->prim_geom + (size_t)i * RT_GEOM_STRIDE;
+        if (s->prim_type[i] == RT_SPHERE) {
+            ref_of_gid[i] = make_ref(RT_SPHERE, (int)gid_sph.size());
+            gid_sph.push_back(i);
+            sph.insert(sph.end(), g, g + 4);
+        } else if (s->prim_type[i] == RT_TRIANGLE) {
+            ref_of_gid[i] = make_ref(RT_TRIANGLE, (int)gid_tri.size());
+            gid_tri.push_back(i);
+            double rec[kTriDoubles];
+            for (int k = 0; k < 3; ++k) {
+                rec[k] = g[k];
+                rec[3 + k] = g[3 + k] - g[k];  // edge1 = v1 - v0 (Triangle.cpp:44)
+                rec[6 + k] = g[6 + k] - g[k];  // edge2 = v2 - v0 (Triangle.cpp:45)
+            }
+            rt::triangle_normal(g, g + 3, g + 6, rec + 9);
+            tri.insert(tri.end(), rec, rec + kTriDoubles);
+        } else {
+            ref_of_gid[i] = make_ref(RT_CYLINDER, (int)gid_cyl.size());
+            gid_cyl.push_back(i);
+            double rec[kCylDoubles];
+            H3 ax = h_normalize(g + 3);  // Cylinder ctor normalizes the axis again (Cylinder.cpp:11)
+            rec[0] = g[0]; rec[1] = g[1]; rec[2] = g[2];
+            rec[3] = ax.x; rec[4] = ax.y; rec[5] = ax.z;
+            rec[6] = g[6];
+            rec[7] = g[7];
+            cyl.insert(cyl.end(), rec, rec + kCylDoubles);
+        }
+    }
+    rt::FlatBVH bvh;
+    if (s->use_bvh) rt::build_flat_bvh(s, bvh);
+
+    SceneView sv;
+    std::memset(&sv, 0, sizeof sv);
+    sv.n_nodes = bvh.size();
+    sv.n_prims = s->n_prims;
+    int off = 0;
+    sv.off_nodes = off; off = align16(off + sv.n_nodes * kNodeBytes);
+    sv.off_sph = off;   off = align16(off + (int)sph.size() * 8);
+    sv.off_tri = off;   off = align16(off + (int)tri.size() * 8);
+    sv.off_cyl = off;   off = align16(off + (int)cyl.size() * 8);
+    sv.off_gid_sph = off; off = align16(off + (int)gid_sph.size() * 4);
+    sv.off_gid_tri = off; off = align16(off + (int)gid_tri.size() * 4);
+    sv.off_gid_cyl = off; off = align16(off + (int)gid_cyl.size() * 4);
+    sv.off_ref = off;     off = align16(off + s->n_prims * 4);
+    sv.image_bytes = std::max(off, 16);
+    std::vector<unsigned char> image((size_t)sv.image_bytes, 0);
+    for (int i = 0; i < sv.n_nodes; ++i) {
+        unsigned char* n = image.data() + sv.off_nodes + (size_t)i * kNodeBytes;
+        std::memcpy(n, &bvh.box[(size_t)i * 6], 48);
+        int ints[4] = {bvh.skip[i], bvh.prim0[i] >= 0 ? ref_of_gid[bvh.prim0[i]] : -1,
+                       bvh.prim1[i] >= 0 ? ref_of_gid[bvh.prim1[i]] : -1, 0};
+        std::memcpy(n + 48, ints, 16);
+    }
+    if (!sph.empty()) std::memcpy(image.data() + sv.off_sph, sph.data(), sph.size() * 8);
+    if (!tri.empty()) std::memcpy(image.data() + sv.off_tri, tri.data(), tri.size() * 8);
+    if (!cyl.empty()) std::memcpy(image.data() + sv.off_cyl, cyl.data(), cyl.size() * 8);
+    if (!gid_sph.empty()) std::memcpy(image.data() + sv.off_gid_sph, gid_sph.data(), gid_sph.size() * 4);
+    if (!gid_tri.empty()) std::memcpy(image.data() + sv.off_gid_tri, gid_tri.data(), gid_tri.size() * 4);
+    if (!gid_cyl.empty()) std::memcpy(image.data() + sv.off_gid_cyl, gid_cyl.data(), gid_cyl.size() * 4);
+    if (s->n_prims) std::memcpy(image.data() + sv.off_ref, ref_of_gid.data(), (size_t)s->n_prims * 4);
+
+    std::vector<DMaterial> mats(s->n_materials);
+    for (int i = 0; i < s->n_materials; ++i) {
+        const rt_material& m = s->materials[i];
+        DMaterial& d = mats[i];
+        d.ks = m.ks; d.kd = m.kd; d.reflectivity = m.reflectivity; d.ior = m.refractive_index;
+        std::memcpy(d.diffuse, m.diffuse, sizeof d.diffuse);
+        std::memcpy(d.specular, m.specular, sizeof d.specular);
+        d.spec_exp = m.specular_exponent;
+        d.reflective = m.is_reflective;
+        d.refractive = m.is_refractive;
+        d.texture = m.texture;
+    }
+    std::vector<int> mat_of_gid(s->prim_material, s->prim_material + s->n_prims);
+    std::vector<DLight> lights(s->n_lights);
+    for (int i = 0; i < s->n_lights; ++i) {
+        const rt_light& l = s->lights[i];
+        DLight& d = lights[i];
+        std::memset(&d, 0, sizeof d);
+        d.type = l.type;
+        std::memcpy(d.intensity, l.intensity, sizeof d.intensity);
+        std::memcpy(d.position, l.position, sizeof d.position);
+        if (l.type == RT_LIGHT_AREA) {  // AreaLight ctor normalizes (include/AreaLight.h:21-22)
+            H3 n = h_normalize(l.normal), u = h_normalize(l.u), v = h_normalize(l.v);
+            d.normal[0] = n.x; d.normal[1] = n.y; d.normal[2] = n.z;
+            d.u[0] = u.x; d.u[1] = u.y; d.u[2] = u.z;
+            d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z;
+        }
+        d.width = l.width;
+        d.height = l.height;
+    }
+    std::vector<DTexture> texs(s->n_textures);
+    std::vector<unsigned char> texels;
+    for (int i = 0; i < s->n_textures; ++i) {
+        const rt_texture& t = s->textures[i];
+        texs[i].width = t.width;
+        texs[i].height = t.height;
+        texs[i].offset = (long long)texels.size();
+        size_t n = (t.width > 0 && t.height > 0 && t.rgb) ? (size_t)t.width * t.height * 3 : 0;
+        if (n == 0) texs[i].width = texs[i].height = 0;
+        else texels.insert(texels.end(), t.rgb, t.rgb + n);
+    }
+
+    int rc;
+    if ((rc = upload(&c->d_image, image)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_materials, mats)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_mat_of_gid, mat_of_gid)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_lights, lights)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_textures, texs)) != RT_OK) return rc;
+    if ((rc = upload(&c->d_texels, texels)) != RT_OK) return rc;
+    sv.image = c->d_image;
+    sv.materials = c->d_materials;
+    sv.mat_of_gid = c->d_mat_of_gid;
+    sv.lights = c->d_lights;
+    sv.n_lights = s->n_lights;
+    sv.textures = c->d_textures;
+    sv.texels = c->d_texels;
+    std::memcpy(sv.bg, s->background, sizeof sv.bg);
+    c->sv = sv;
+    c->n_bvh_nodes = sv.n_nodes;
+    c->have_scene = true;
+    c->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context* c, const rt_camera* cam) {
+    if (!c || !cam) return rt::set_error(RT_ERR_INVALID, "rt_set_camera: null argument");
+    c->cam = *cam;
+    c->have_camera = true;
+    return RT_OK;
+}
+
+int rt_set_params(rt_context* c, const rt_params* p) {
+    if (!c || !p) return rt::set_error(RT_ERR_INVALID, "rt_set_params: null argument");
+    if (p->width < 2 || p->height < 2)
+        return rt::set_error(RT_ERR_INVALID, "rt_set_params: width and height must be >= 2 (u = i/(W-1))");
+    if (p->mode < RT_MODE_PHONG || p->mode > RT_MODE_PATHTRACE) return rt::set_error(RT_ERR_INVALID, "rt_set_params: mode %d", p->mode);
+    if (p->tonemap < RT_TONEMAP_NONE || p->tonemap > RT_TONEMAP_UNCHARTED2)
+        return rt::set_error(RT_ERR_INVALID, "rt_set_params: tonemap %d", p->tonemap);
+    if (p->max_depth < 0 || p->max_depth > kMaxDepthLimit)
+        return rt::set_error(RT_ERR_LIMIT, "rt_set_params: max_depth %d outside [0, %d]", p->max_depth, kMaxDepthLimit);
+    if (p->mode == RT_MODE_PATHTRACE && p->max_depth > 30)
+        return rt::set_error(RT_ERR_LIMIT, "rt_set_params: path trace max_depth %d > 30 (RNG node code is 32 bits)", p->max_depth);
+    if (p->band_rows <= 0 || p->band_world <= 0 || p->band_rank < 0 || p->band_rank >= p->band_world)
+        return rt::set_error(RT_ERR_INVALID, "rt_set_params: band partition %d/%d rows %d", p->band_rank, p->band_world, p->band_rows);
+    c->params = *p;
+    c->sqrt_spp = 0;
+    if (p->mode == RT_MODE_PATHTRACE) {
+        if (p->pixel_samples < 0) return rt::set_error(RT_ERR_INVALID, "rt_set_params: pixel_samples %d", p->pixel_samples);
+        c->sqrt_spp = static_cast<int>(std::sqrt((double)p->pixel_samples));  // RayTracer.cpp:255
+    }
+    c->have_params = true;
+    return RT_OK;
+}
+
+int64_t rt_local_rows(const rt_context* c) {
+    if (!c || !c->have_params) return rt::set_error(RT_ERR_STATE, "rt_local_rows: params not set");
+    return local_rows_of(c->params);
+}
+
+int rt_render_device(rt_context* c, void* stream, double* rgb_dev, int32_t* hit_id_dev) {
+    if (!c || !rgb_dev) return rt::set_error(RT_ERR_INVALID, "rt_render_device: null argument");
+    return launch_render(c, (hipStream_t)stream, rgb_dev, hit_id_dev, false);
+}
+
+int rt_pathtrace_accumulate_device(rt_context* c, void* stream, double* accum_dev) {
+    if (!c || !accum_dev) return rt::set_error(RT_ERR_INVALID, "rt_pathtrace_accumulate_device: null argument");
+    if (!c->have_params || c->params.mode != RT_MODE_PATHTRACE)
+        return rt::set_error(RT_ERR_STATE, "rt_pathtrace_accumulate_device: mode is not path trace");
+    return launch_render(c, (hipStream_t)stream, accum_dev, nullptr, true);
+}
+
+int rt_pathtrace_resolve_device(rt_context* c, void* stream, double* accum_dev, int64_t n_pixels) {
+    if (!c || !accum_dev || n_pixels < 0) return rt::set_error(RT_ERR_INVALID, "rt_pathtrace_resolve_device: bad argument");
+    if (!c->have_params) return rt::set_error(RT_ERR_STATE, "rt_pathtrace_resolve_device: params not set");
+    if (n_pixels == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int block = 256;
+    long long grid = (n_pixels + block - 1) / block;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, accum_dev, (long long)n_pixels,
+                       c->params.pixel_samples, c->params.tonemap, c->params.exposure);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(rt_context* c, double* rgb, int32_t* hit_id) {
+    if (!c || !rgb) return rt::set_error(RT_ERR_INVALID, "rt_render: null argument");
+    if (!c->have_params) return rt::set_error(RT_ERR_STATE, "rt_render: params not set");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t n_px = (size_t)local_rows_of(c->params) * c->params.width;
+    double* d_rgb = nullptr;
+    int* d_hit = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rgb, std::max<size_t>(n_px, 1) * 3 * sizeof(double)));
+    if (hit_id) {
+        hipError_t e = hipMalloc((void**)&d_hit, std::max<size_t>(n_px, 1) * sizeof(int));
+        if (e != hipSuccess) {
+            (void)hipFree(d_rgb);
+            return rt::set_error(RT_ERR_DEVICE, "rt_render: hipMalloc(hit_id) -> %s", hipGetErrorString(e));
+        }
+        (void)hipMemset(d_hit, 0xFF, std::max<size_t>(n_px, 1) * sizeof(int));
+    }
+    int rc = launch_render(c, nullptr, d_rgb, d_hit, false);
+    if (rc == RT_OK) {
+        hipError_t e = hipMemcpy(rgb, d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && hit_id) e = hipMemcpy(hit_id, d_hit, n_px * sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = rt::set_error(RT_ERR_DEVICE, "rt_render: kernel or copy failed -> %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_hit);
+    return rc;
+}
+
+int rt_get_stats(rt_context* c, rt_stats* out) {
+    if (!c || !out) return rt::set_error(RT_ERR_INVALID, "rt_get_stats: null argument");
+    std::memset(out, 0, sizeof *out);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->timed) {
+        HIP_TRY(hipEventSynchronize(c->ev_stop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        out->kernel_ms = ms;
+        unsigned long long cnt[4];
+        HIP_TRY(hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+        out->rays = cnt[0];
+        out->box_tests = cnt[1];
+        out->prim_tests = cnt[2];
+    }
+    out->upload_ms = c->upload_ms;
+    out->n_bvh_nodes = c->n_bvh_nodes;
+    out->scene_in_lds = c->scene_in_lds;
+    return RT_OK;
+}
+
+// ---- diagnostics (declared in the "diagnostics" section of the header) --------------------------
+int rt_debug_trace_rays(rt_context* c, int64_t n, const double* origins, const double* dirs, double* t_out,
+                        int32_t* prim_out, double* normal_out) {
+    if (!c || n < 0 || !origins || !dirs || !t_out || !prim_out || !normal_out)
+        return rt::set_error(RT_ERR_INVALID, "rt_debug_trace_rays: bad argument");
+    if (!c->have_scene) return rt::set_error(RT_ERR_STATE, "rt_debug_trace_rays: no scene");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    double *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr;
+    int* d_p = nullptr;
+    size_t v3 = (size_t)n * 3 * sizeof(double);
+    int rc = RT_OK;
+    hipError_t e = hipMalloc((void**)&d_o, v3);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_d, v3);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_t, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_n, v3);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_p, (size_t)n * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_o, origins, v3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, dirs, v3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        int block = 256;
+        long long grid = (n + block - 1) / block;
+        hipLaunchKernelGGL(debug_trace_kernel, dim3((unsigned)grid), dim3(block), 0, 0, c->sv, (long long)n, d_o, d_d, d_t, d_p, d_n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(t_out, d_t, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(prim_out, d_p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(normal_out, d_n, v3, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = rt::set_error(RT_ERR_DEVICE, "rt_debug_trace_rays -> %s", hipGetErrorString(e));
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_n); (void)hipFree(d_p);
+    return rc;
+}
+
+int rt_debug_math(rt_context* c, int op, int64_t n, const double* a, const double* b, double* out) {
+    if (!c || n < 0 || !a || !out) return rt::set_error(RT_ERR_INVALID, "rt_debug_math: bad argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    double *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    size_t bytes = (size_t)n * sizeof(double);
+    int rc = RT_OK;
+    hipError_t e = hipMalloc((void**)&d_a, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_o, bytes);
+    if (e == hipSuccess && b) e = hipMalloc((void**)&d_b, bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        int block = 256;
+        long long grid = (n + block - 1) / block;
+        hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)grid), dim3(block), 0, 0, op, (long long)n, d_a, d_b, d_o);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = rt::set_error(RT_ERR_DEVICE, "rt_debug_math -> %s", hipGetErrorString(e));
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
+    return rc;
+}
+
+}  // extern "C"
