@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X render loop (driver contract in the task brief).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload clutter_500_4k|pathtrace_1080p]
+
+A "step" is one pass of the hot path over one frame of the workload:
+
+  clutter_500_4k   (default; BASELINE.json configs[2]) scenes/clutter_500.json at 3840x2160,
+                   Whitted ("phong") mode, nbounces 8, BVH tie rule (the reference renders the
+                   same bytes with "bvh": false as shipped).  Metric: Mrays/s,
+                   ray = one closest-hit query = one Scene::intersect call of the reference.
+  pathtrace_1080p  (configs[3]) scenes/pathtrace.json at 1920x1080, lightSamples 16, with
+                   --spp strata per step (default 16; the 1024-spp frame is 64 such steps --
+                   samples are independent, so spp/s does not depend on the count).
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) ONE frame is split over the
+ranks -- row bands for Whitted, strata ranges for path tracing -- and recombined on rank 0's
+device through RCCL (gather of disjoint bands / reduce of partial sums), inside the timed region.
+Total work is fixed, so "scaling" is "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the persistent render kernel against the fp64
+VALU peak WITHOUT FMA credit (contraction is off for parity): algorithmic ops = 24 per box test
++ 33 per sphere + 62 per triangle + 150 per cylinder test, counted in the
+reference's traversal order -- which is exactly the order this kernel walks.  `cpu_baseline` is
+the pinned fp64 CPU restatement (oracle/) on the same frame on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
+
+FP64_VALU_PEAK_TOPS = 78.6 / 2.0  # MI355X fp64 vector 78.6 TFLOP/s counts an FMA as 2; no FMA credit here
+OPS_BOX, OPS_SPHERE, OPS_TRI, OPS_CYL = 24, 33, 62, 150
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="clutter_500_4k", choices=["clutter_500_4k", "pathtrace_1080p"])
+    ap.add_argument("--spp", type=int, default=16, help="path trace: strata per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import raytracer_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    pathtrace = args.workload == "pathtrace_1080p"
+    if pathtrace:
+        sf = rt.SceneFile("scenes/pathtrace.json", width=1920, height=1080)
+        base = sf.params
+        side = int(np.sqrt(args.spp))
+        base.pixel_samples, base.light_samples = side * side, 16
+        desc = sf.desc
+    else:
+        sf = rt.SceneFile("scenes/clutter_500.json", width=3840, height=2160)
+        base = sf.params
+        desc = sf.desc
+        desc.use_bvh = 1
+    W, H = base.width, base.height
+
+    r = rt.Renderer(local_rank)
+    r.upload(desc)
+    r.set_camera(sf.camera)
+    P = rt.copy_params(base)
+    if pathtrace:
+        n_strata = base.pixel_samples
+        lo = (n_strata * rank) // world
+        hi = (n_strata * (rank + 1)) // world
+        # an empty share (more ranks than strata) is the range [n, n): sample_end <= 0 would mean "all"
+        P.sample_begin, P.sample_end = (lo, hi) if hi > lo else (n_strata, n_strata)
+    else:
+        P.band_rank, P.band_world = rank, world
+    r.set_params(P)
+    rows = r.local_rows
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if pathtrace:
+        accum = torch.empty(H * W * 3, dtype=torch.float64, device=dev)
+        out = accum
+    else:
+        # equal-sized gather slots: every rank's compact band buffer padded to the largest
+        band = P.band_rows
+        n_bands = (H + band - 1) // band
+        max_rows = ((n_bands + world - 1) // world) * band
+        mine = torch.zeros(max_rows * W * 3, dtype=torch.float64, device=dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)] if (world > 1 and rank == 0) else None
+        frame = torch.empty(H, W, 3, dtype=torch.float64, device=dev) if rank == 0 else None
+        row_index = None
+        if world > 1 and rank == 0:
+            # destination rows of rank q's compact rows, for the scatter into the frame
+            row_index = []
+            for q in range(world):
+                rws = [j for b in range(q, n_bands, world) for j in range(b * band, min(H, (b + 1) * band))]
+                row_index.append(torch.tensor(rws, dtype=torch.long, device=dev))
+
+    def step():
+        if pathtrace:
+            r.accumulate_device(accum.data_ptr(), stream=stream)
+            if world > 1:
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                r.resolve_device(accum.data_ptr(), H * W, stream=stream)
+        else:
+            r.render_device(mine.data_ptr(), None, stream=stream)
+            if world > 1:
+                dist.gather(mine, gathered, dst=0)
+                if rank == 0:
+                    for q in range(world):
+                        n = row_index[q].numel()
+                        frame.index_copy_(0, row_index[q], gathered[q][: n * W * 3].view(n, W, 3))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    kernel_ms = []
+    rays_local = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-launch HIP-event time of the render kernel on its own stream (rt_get_stats waits on the
+        # event recorded right after the kernel; the following collective is already enqueued)
+        st = r.stats()
+        kernel_ms.append(st.kernel_ms)
+        rays_local = st.rays
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    st = r.stats()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([st.rays, st.box_tests, st.sphere_tests, st.triangle_tests, st.cylinder_tests],
+                       dtype=torch.float64, device=dev)
+    kms = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    rays, boxes, sph, tri, cyl = (float(x) for x in cnt.tolist())
+    k_ms = float(kms.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays * args.steps / elapsed / 1e6
+        alg_ops = OPS_BOX * boxes + OPS_SPHERE * sph + OPS_TRI * tri + OPS_CYL * cyl  # per frame, all ranks
+        achieved = alg_ops / world / (k_ms * 1e-3) / 1e12  # per GPU: ops of one launch / its duration
+        line = {
+            "metric": "Mrays/s" if not pathtrace else "spp/s",
+            "value": mrays if not pathtrace else (base.pixel_samples / (elapsed / args.steps)),
+            "unit": "Mrays/s" if not pathtrace else "spp/s at 1920x1080",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "reference scene file (scenes/%s.json), resized" %
+                                                         ("pathtrace" if pathtrace else "clutter_500"),
+            "config": {"workload": ("pathtrace.json 1920x1080, %d strata/step, 16 light samples" % base.pixel_samples)
+                       if pathtrace else "clutter_500.json 3840x2160 Whitted nbounces=8, BVH tie rule",
+                       "rays_per_step": rays, "mrays_per_s": mrays,
+                       "parallelism": ("strata-range x%d + RCCL reduce" if pathtrace else "row-band x%d + RCCL gather") % world},
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VALU_PEAK_TOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
+                         "kernel": "render_kernel<LDS>", "kernel_ms": k_ms,
+                         "ops_per_ray": alg_ops / max(rays, 1.0),
+                         "note": "fp64 ops without FMA credit (contraction off for parity); peak = 78.6/2"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(sf, desc, base, pathtrace)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sf, desc, base, pathtrace):
+    """The pinned oracle (oracle/liboracle.so, -O2 -fopenmp) on this box's host cores: checker code
+    used here only as the reported baseline."""
+    import raytracer_amd as rt
+    from tests import oracle_lib
+    threads = min(oracle_lib.load().oracle_max_threads(), os.cpu_count() or 1)
+    P = rt.copy_params(base)
+    if pathtrace:
+        P.width, P.height = 480, 270  # bounded sample: 1/16 of the frame's pixels, same strata
+        sf.resize(480, 270)
+        sample = "480x270 crop-equivalent (1/16 of the pixels), all strata of one step"
+    else:
+        sample = "the full 3840x2160 frame, rendered repeatedly for >= 10 s"
+    t0 = time.perf_counter()
+    n = 0
+    rays = 0
+    while True:
+        _, _, cnt, _ = oracle_lib.render(desc, sf.camera, P, want_hit=False, threads=threads)
+        rays += cnt["rays"]
+        n += 1
+        if time.perf_counter() - t0 > 10.0 or n >= 50:
+            break
+    dt = time.perf_counter() - t0
+    if pathtrace:
+        value = P.pixel_samples * n / dt / 16.0  # spp/s referred to the full 1080p frame
+        unit = "spp/s at 1920x1080"
+    else:
+        value = rays / dt / 1e6
+        unit = "Mrays/s"
+    return {"value": value, "unit": unit, "cores": threads, "kind": "port",
+            "sample": sample + f" ({n} frames, {dt:.1f} s)",
+            "note": "our fp64 CPU restatement, byte-identical to the reference; the reference itself, as built "
+                    "by its Makefile, measured 0.6-2.1 Mrays/s on 8 cores (BASELINE.md)"}
+
+
+if __name__ == "__main__":
+    main()

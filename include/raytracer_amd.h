@@ -153,6 +153,9 @@ typedef struct rt_stats {
                               calls the reference would make, src/Scene.cpp:63)                */
     uint64_t box_tests;    /* BoundingBox::intersect evaluations actually executed            */
     uint64_t prim_tests;   /* primitive intersect evaluations actually executed               */
+    uint64_t sphere_tests; /* ... of which Sphere::intersect                                   */
+    uint64_t triangle_tests; /* ... Triangle::intersect                                        */
+    uint64_t cylinder_tests; /* ... Cylinder::intersect                                        */
     double kernel_ms;      /* HIP-event time of the last render's kernels on their stream     */
     double upload_ms;      /* last scene upload (host flatten + H2D)                           */
     int32_t n_bvh_nodes;   /* flattened BVH nodes (0 in linear mode)                           */

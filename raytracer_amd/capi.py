@@ -77,6 +77,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("rays", C.c_uint64), ("box_tests", C.c_uint64), ("prim_tests", C.c_uint64),
+        ("sphere_tests", C.c_uint64), ("triangle_tests", C.c_uint64), ("cylinder_tests", C.c_uint64),
         ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
         ("n_bvh_nodes", C.c_int32), ("scene_in_lds", C.c_int32),
     ]
@@ -125,6 +126,14 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If this library
+    # pulled in /opt/rocm's copy first, torch.cuda would later find "No HIP GPUs".  Importing torch
+    # first lets the loader bind our NEEDED libamdhip64 to the copy torch already mapped.
+    if os.environ.get("RT_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(p):
         raise RtError(
             f"{p} not found: build it with `make -C raytracer_amd/csrc` "

@@ -116,7 +116,7 @@ struct RenderArgs {
     double* frames;           // [max_depth+1][kNF][n_threads]
     long long frame_stride;   // n_threads
     unsigned int* ticket;
-    unsigned long long* counters;  // rays, box tests, prim tests
+    unsigned long long* counters;  // rays, box, sphere, triangle, cylinder tests
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -128,17 +128,24 @@ struct HitT {
     int part;  // cylinder part
 };
 
+struct Tally {
+    unsigned rays, box, sph, tri, cyl;
+};
+
 template <typename P>
-RT_DEV bool prim_t(P img, const SceneView& sv, int ref, D3 o, D3 d, double& t, int& part) {
+RT_DEV bool prim_t(P img, const SceneView& sv, int ref, D3 o, D3 d, double& t, int& part, Tally& tally) {
     int type = ref_type(ref), idx = ref_index(ref);
     part = 0;
+    if (type == RT_SPHERE) ++tally.sph;
+    else if (type == RT_TRIANGLE) ++tally.tri;
+    else ++tally.cyl;
     if (type == RT_SPHERE) return sphere_t((const double*)(img + sv.off_sph) + idx * kSphereDoubles, o, d, t);
     if (type == RT_TRIANGLE) return triangle_t((const double*)(img + sv.off_tri) + idx * kTriDoubles, o, d, t);
     return cylinder_t((const double*)(img + sv.off_cyl) + idx * kCylDoubles, o, d, t, part);
 }
 
 template <typename P>
-RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, unsigned& n_box, unsigned& n_prim) {
+RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
     HitT best;
     best.ref = -1;
     best.part = 0;
@@ -151,20 +158,18 @@ RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, unsigned& n_box,
             const double* nb = (const double*)(img + sv.off_nodes + i * kNodeBytes);
             const int* ni = (const int*)(nb + 6);
             int skip = ni[0], r0 = ni[1], r1 = ni[2];
-            ++n_box;
+            ++tally.box;
             bool hit = box_hit(nb, o, d);
             if (hit && r0 >= 0) {
                 double t;
                 int part;
-                ++n_prim;
-                if (prim_t(img, sv, r0, o, d, t, part) && !(best.t < t)) {
+                if (prim_t(img, sv, r0, o, d, t, part, tally) && !(best.t < t)) {
                     best.t = t;
                     best.ref = r0;
                     best.part = part;
                 }
                 if (r1 >= 0) {
-                    ++n_prim;
-                    if (prim_t(img, sv, r1, o, d, t, part) && !(best.t < t)) {
+                    if (prim_t(img, sv, r1, o, d, t, part, tally) && !(best.t < t)) {
                         best.t = t;
                         best.ref = r1;
                         best.part = part;
@@ -181,8 +186,7 @@ RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, unsigned& n_box,
             int r = refs[k];
             double t;
             int part;
-            ++n_prim;
-            if (prim_t(img, sv, r, o, d, t, part) && t < best.t) {
+            if (prim_t(img, sv, r, o, d, t, part, tally) && t < best.t) {
                 best.t = t;
                 best.ref = r;
                 best.part = part;
@@ -693,6 +697,11 @@ RT_DEV void pt_next_sample(const RenderArgs& A, const Frames& F, Lane& L, Rng& r
         L.kind = RAY_NONE;
         return;
     }
+    if (A.max_depth <= 0) {  // traceRayPath(ray, 0) returns 0 without tracing (RayTracer.cpp:507-509)
+        L.sample = A.s_end;
+        pt_next_sample(A, F, L, rng);
+        return;
+    }
     int s = L.sample;
     int sx = s % A.sqrt_spp, sy = s / A.sqrt_spp;
     rng.sample = (unsigned)s;
@@ -993,7 +1002,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(SceneView sv, RenderArgs
     rng.k0 = A.seed_lo;
     rng.k1 = A.seed_hi;
     rng.pixel = rng.sample = 0;
-    unsigned n_rays = 0, n_box = 0, n_prim = 0;
+    Tally tally = {0, 0, 0, 0, 0};
 
     for (;;) {
         // refill: lanes without a ray pull the next pixel ticket (8x8 tiles of the local rows)
@@ -1015,6 +1024,10 @@ __global__ void __launch_bounds__(kBlock) render_kernel(SceneView sv, RenderArgs
                 F.put3(A.max_depth, 0, mk(0, 0, 0));
                 L.sample = A.s_begin;
                 pt_next_sample(A, F, L, rng);  // may finish the pixel at once when the range is empty
+            } else if (A.max_depth <= 0) {
+                // traceRay(ray, 0) returns the background before intersecting (RayTracer.cpp:374-377)
+                if (A.hit_id) A.hit_id[(long long)lrow * A.W + px] = -1;
+                finish_pixel_whitted<const unsigned char*>(A, L, ld3(sv.bg));
             } else {  // RayTracer.cpp:217-220
                 double u = 1.0 - ((double)px / (A.W - 1));
                 double v = (double)j / (A.H - 1);
@@ -1027,25 +1040,19 @@ __global__ void __launch_bounds__(kBlock) render_kernel(SceneView sv, RenderArgs
         if (!__any(L.kind != RAY_NONE)) break;  // every lane is out of work and out of tickets
 
         if (L.kind != RAY_NONE) {
-            ++n_rays;
-            HitT h = closest_hit(img, sv, L.o, L.d, n_box, n_prim);
+            ++tally.rays;
+            HitT h = closest_hit(img, sv, L.o, L.d, tally);
             if (A.mode == RT_MODE_PATHTRACE) advance_path(img, sv, A, F, L, rng, h);
             else advance_whitted(img, sv, A, F, L, h);
         }
     }
 
     // one atomic per wave per counter
-    unsigned long long r = n_rays, b = n_box, p = n_prim;
-    for (int off = 32; off > 0; off >>= 1) {
-        r += __shfl_down(r, off);
-        b += __shfl_down(b, off);
-        p += __shfl_down(p, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&A.counters[0], r);
-        atomicAdd(&A.counters[1], b);
-        atomicAdd(&A.counters[2], p);
-    }
+    unsigned long long c[5] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl};
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 5; ++k) c[k] += __shfl_down(c[k], off);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 5; ++k) atomicAdd(&A.counters[k], c[k]);
 }
 
 // RayTracer.cpp:301-315 on a flat buffer
@@ -1072,8 +1079,8 @@ __global__ void debug_trace_kernel(SceneView sv, long long n, const double* orig
     const unsigned char* img = sv.image;
     D3 o = ld3(origins + 3 * k);
     D3 d = normalize(ld3(dirs + 3 * k));
-    unsigned nb = 0, np = 0;
-    HitT h = closest_hit(img, sv, o, d, nb, np);
+    Tally tally = {0, 0, 0, 0, 0};
+    HitT h = closest_hit(img, sv, o, d, tally);
     if (h.ref >= 0) {
         D3 point, normal;
         hit_geometry(img, sv, h, o, d, point, normal);
@@ -1272,7 +1279,7 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     A.frame_stride = n_threads;
 
     HIP_TRY(hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (lds) {
         if (lds_bytes > 48 * 1024)
@@ -1319,7 +1326,7 @@ int rt_create(rt_context** out, int device) {
     c->n_cus = prop.multiProcessorCount;
     std::memset(&c->sv, 0, sizeof c->sv);
     hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
-    hipError_t b = hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long));
+    hipError_t b = hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long));
     hipError_t s0 = hipEventCreate(&c->ev_start);
     hipError_t s1 = hipEventCreate(&c->ev_stop);
     if (a != hipSuccess || b != hipSuccess || s0 != hipSuccess || s1 != hipSuccess) {
@@ -1585,11 +1592,14 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
         out->kernel_ms = ms;
-        unsigned long long cnt[4];
+        unsigned long long cnt[8];
         HIP_TRY(hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
         out->rays = cnt[0];
         out->box_tests = cnt[1];
-        out->prim_tests = cnt[2];
+        out->sphere_tests = cnt[2];
+        out->triangle_tests = cnt[3];
+        out->cylinder_tests = cnt[4];
+        out->prim_tests = cnt[2] + cnt[3] + cnt[4];
     }
     out->upload_ms = c->upload_ms;
     out->n_bvh_nodes = c->n_bvh_nodes;

@@ -1,0 +1,120 @@
+"""Helpers shared by the tests: loading shipped scenes and building synthetic ones as rt_scene_desc."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import raytracer_amd as rt
+from raytracer_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def scene_path(name):
+    return os.path.join(ROOT, "scenes", name + ".json")
+
+
+def load(name, width=None, height=None, tonemap=None):
+    return rt.SceneFile(scene_path(name), tonemap=tonemap, width=width, height=height)
+
+
+class SyntheticScene:
+    """Owns numpy arrays and exposes them as a capi.SceneDesc (keeps the arrays alive)."""
+
+    def __init__(self, prim_type, prim_geom, materials=None, lights=None, background=(0.1, 0.2, 0.3), use_bvh=1,
+                 prim_material=None):
+        n = len(prim_type)
+        self.prim_type = np.ascontiguousarray(prim_type, dtype=np.int32)
+        self.prim_geom = np.ascontiguousarray(prim_geom, dtype=np.float64).reshape(n, capi.RT_GEOM_STRIDE)
+        mats = materials or [default_material()]
+        self.materials = (capi.Material * len(mats))(*mats)
+        self.prim_material = np.ascontiguousarray(
+            prim_material if prim_material is not None else np.zeros(n, dtype=np.int32), dtype=np.int32)
+        ls = lights or []
+        self.lights = (capi.Light * max(len(ls), 1))(*ls)
+        d = capi.SceneDesc()
+        d.n_prims, d.n_materials, d.n_textures, d.n_lights = n, len(mats), 0, len(ls)
+        d.prim_type = self.prim_type.ctypes.data_as(C.POINTER(C.c_int32))
+        d.prim_material = self.prim_material.ctypes.data_as(C.POINTER(C.c_int32))
+        d.prim_geom = self.prim_geom.ctypes.data_as(C.POINTER(C.c_double))
+        d.materials = C.cast(self.materials, C.POINTER(capi.Material))
+        d.textures = None
+        d.lights = C.cast(self.lights, C.POINTER(capi.Light))
+        d.background = capi.d3(*background)
+        d.use_bvh = use_bvh
+        self.desc = d
+
+
+def default_material(diffuse=(0.7, 0.6, 0.5), specular=(1, 1, 1), ks=0.3, kd=0.8, exp=20, reflective=0,
+                     reflectivity=0.0, refractive=0, ior=1.0):
+    m = capi.Material()
+    m.ks, m.kd, m.reflectivity, m.refractive_index = ks, kd, reflectivity, ior
+    m.diffuse = capi.d3(*diffuse)
+    m.specular = capi.d3(*specular)
+    m.specular_exponent, m.is_reflective, m.is_refractive, m.texture = exp, reflective, refractive, -1
+    return m
+
+
+def point_light(pos, intensity=(1, 1, 1)):
+    l = capi.Light()
+    l.type = capi.RT_LIGHT_POINT
+    l.position = capi.d3(*pos)
+    l.intensity = capi.d3(*intensity)
+    return l
+
+
+def area_light(pos, normal, u, v, w, h, intensity=(5, 5, 5)):
+    l = capi.Light()
+    l.type = capi.RT_LIGHT_AREA
+    l.position, l.normal, l.u, l.v = capi.d3(*pos), capi.d3(*normal), capi.d3(*u), capi.d3(*v)
+    l.width, l.height = w, h
+    l.intensity = capi.d3(*intensity)
+    return l
+
+
+def random_prims(rng, n_sph, n_tri, n_cyl, extent=4.0, axis_aligned_cyl=False):
+    """Random soup in [-extent, extent]^3; cylinders get arbitrary axes (so the reference's +Y
+    bounding box quirk is exercised) unless axis_aligned_cyl."""
+    types, geom = [], []
+    for _ in range(n_sph):
+        g = np.zeros(capi.RT_GEOM_STRIDE)
+        g[:3] = rng.uniform(-extent, extent, 3)
+        g[3] = rng.uniform(0.1, 0.8)
+        types.append(capi.RT_SPHERE); geom.append(g)
+    for _ in range(n_tri):
+        g = np.zeros(capi.RT_GEOM_STRIDE)
+        c = rng.uniform(-extent, extent, 3)
+        g[0:3] = c + rng.uniform(-1, 1, 3)
+        g[3:6] = c + rng.uniform(-1, 1, 3)
+        g[6:9] = c + rng.uniform(-1, 1, 3)
+        types.append(capi.RT_TRIANGLE); geom.append(g)
+    for _ in range(n_cyl):
+        g = np.zeros(capi.RT_GEOM_STRIDE)
+        g[:3] = rng.uniform(-extent, extent, 3)
+        ax = np.array([0.0, 1.0, 0.0]) if axis_aligned_cyl else rng.standard_normal(3)
+        g[3:6] = ax / np.linalg.norm(ax)
+        g[6] = rng.uniform(0.1, 0.5)
+        g[7] = rng.uniform(0.2, 1.5)
+        types.append(capi.RT_CYLINDER); geom.append(g)
+    order = rng.permutation(len(types))
+    return np.array(types, dtype=np.int32)[order], np.array(geom)[order]
+
+
+def look_at(pos, target, up=(0, 1, 0), fov=45.0, aspect=1.5, aperture=0.0, focus=None):
+    cam = capi.Camera()
+    if focus is None:
+        focus = float(np.linalg.norm(np.array(target, dtype=float) - np.array(pos, dtype=float)))
+    capi.check(capi.load().rt_camera_look_at(C.byref(cam), capi.d3(*pos), capi.d3(*target), capi.d3(*up), fov, aspect,
+                                             aperture, focus))
+    return cam
+
+
+def make_params(width, height, mode=capi.RT_MODE_PHONG, max_depth=5, pixel_samples=4, light_samples=2, tonemap=0,
+                exposure=1.0, seed=0):
+    p = capi.Params()
+    p.width, p.height, p.mode, p.tonemap, p.max_depth = width, height, mode, tonemap, max_depth
+    p.pixel_samples, p.light_samples = pixel_samples, light_samples
+    p.exposure, p.shadow_bias, p.seed = exposure, 1e-4, seed
+    p.band_rows, p.band_rank, p.band_world = 8, 0, 1
+    p.sample_begin, p.sample_end = 0, 0
+    return p

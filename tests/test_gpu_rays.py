@@ -1,0 +1,120 @@
+"""Scene::intersect parity ray by ray (rt_debug_trace_rays vs the oracle) and device math exactness."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib, scene_util
+
+pytestmark = pytest.mark.gpu
+
+
+def compare_rays(renderer, desc, o, d):
+    renderer.upload(desc)
+    t, prim, nrm = renderer.trace_rays(o, d)
+    ot, oprim, onrm = oracle_lib.trace_rays(desc, o, d)
+    assert np.array_equal(prim, oprim), f"{(prim != oprim).sum()} of {len(prim)} primitive IDs differ"
+    assert np.array_equal(t, ot)          # bit-exact t (division and sqrt are correctly rounded)
+    assert np.array_equal(nrm, onrm)
+    return prim
+
+
+def test_division_and_sqrt_are_correctly_rounded(renderer):
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    a = rng.standard_normal(n) * np.exp(rng.uniform(-200, 200, n))
+    b = rng.standard_normal(n) * np.exp(rng.uniform(-200, 200, n))
+    a[:8] = [0.0, -0.0, 1.0, np.inf, -np.inf, 0.0, 5e-324, 1e308]
+    b[:8] = [0.0, 1.0, 0.0, 2.0, -0.0, -3.0, 3.0, 1e-308]
+    with np.errstate(all="ignore"):
+        expect = a / b
+    got = renderer.math(0, a, b)
+    assert np.array_equal(got, expect, equal_nan=True)
+    assert np.array_equal(np.signbit(got), np.signbit(expect))
+    x = np.abs(a)
+    assert np.array_equal(renderer.math(1, x), np.sqrt(x))
+
+
+def test_transcendentals_within_a_few_ulp(renderer):
+    """pow/atan2/acos/cos/sin of the device library are not bit-identical to glibc; the contract only
+    needs colours within 1e-4.  Measured: <= 2 ulp."""
+    rng = np.random.default_rng(12)
+    n = 1_000_000
+    base, ex = rng.uniform(0, 1, n), rng.integers(1, 200, n).astype(np.float64)
+    for op, a, b, ref in [(2, base, ex, np.power(base, ex)),
+                          (3, rng.standard_normal(n), rng.standard_normal(n), None),
+                          (4, rng.uniform(-1, 1, n), None, None),
+                          (5, rng.uniform(0, 6.3, n), None, None), (6, rng.uniform(0, 6.3, n), None, None)]:
+        if ref is None:
+            ref = {3: lambda: np.arctan2(a, b), 4: lambda: np.arccos(a), 5: lambda: np.cos(a), 6: lambda: np.sin(a)}[op]()
+        got = renderer.math(op, a, b)
+        ulp = np.abs(got - ref) / np.maximum(np.spacing(np.abs(ref)), 5e-324)
+        assert ulp.max() <= 4, (op, ulp.max())
+
+
+def test_device_rng_equals_oracle_rng(renderer):
+    lib = oracle_lib.load()
+    pix = np.arange(0, 5000, dtype=np.float64)
+    smp = (np.arange(0, 5000) % 37).astype(np.float64)
+    got = renderer.math(7, pix, smp)
+    expect = np.array([lib.oracle_uniform(0, int(p), int(s), 1, 0) for p, s in zip(pix, smp)])
+    assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("name,bvh", [("clutter_500", 1), ("clutter_500", 0), ("final", 1), ("mirror_glass_cylinder", 1),
+                                      ("binary_primitives", 1), ("umbrella", 1)])
+def test_random_rays_on_shipped_scenes(renderer, name, bvh):
+    sf = scene_util.load(name)
+    desc = sf.desc
+    desc.use_bvh = bvh
+    rng = np.random.default_rng(21)
+    n = 200_000 if bvh else 20_000
+    o = rng.uniform(-3, 3, (n, 3)) + np.array([0, 1, 0])
+    d = rng.standard_normal((n, 3))
+    prim = compare_rays(renderer, desc, o, d)
+    assert (prim >= 0).mean() > 0.001  # binary_primitives is three small objects
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("bvh", [0, 1])
+def test_random_rays_on_random_soups(renderer, seed, bvh):
+    rng = np.random.default_rng(40 + seed)
+    types, geom = scene_util.random_prims(rng, 60, 60, 25)
+    s = scene_util.SyntheticScene(types, geom, use_bvh=bvh)
+    n = 100_000
+    o = rng.uniform(-6, 6, (n, 3))
+    d = rng.standard_normal((n, 3))
+    compare_rays(renderer, s.desc, o, d)
+
+
+def test_degenerate_rays(renderer):
+    """Axis-parallel rays (zero direction components -> +-inf and NaN slabs), origins on box planes,
+    origins inside primitives, rays grazing spheres and running along triangle edges."""
+    rng = np.random.default_rng(50)
+    types, geom = scene_util.random_prims(rng, 20, 20, 10)
+    # add axis-aligned geometry with exactly representable coordinates
+    extra_t = [1, 1, 0, 2]
+    extra_g = np.zeros((4, 12))
+    extra_g[0, :9] = [0, 0, 2, 1, 0, 2, 0, 1, 2]          # triangle in the z = 2 plane
+    extra_g[1, :9] = [-1, -0.5, -1, 1, -0.5, -1, 1, -0.5, 1]  # floor triangle
+    extra_g[2, :4] = [0, 0, -3, 1]                        # unit sphere
+    extra_g[3, :8] = [2, 0, 0, 0, 1, 0, 0.5, 1.0]         # +Y cylinder
+    types = np.concatenate([types, np.array(extra_t, dtype=np.int32)])
+    geom = np.concatenate([geom, extra_g])
+    o_list, d_list = [], []
+    axes = np.eye(3)
+    for ax in range(3):
+        for sgn in (1.0, -1.0):
+            oo = rng.integers(-4, 5, (3000, 3)).astype(np.float64) * 0.5   # many land exactly on box planes
+            o_list.append(oo)
+            d_list.append(np.tile(axes[ax] * sgn, (3000, 1)))
+    # rays in coordinate planes (one zero component)
+    oo = rng.integers(-4, 5, (6000, 3)).astype(np.float64) * 0.25
+    dd = rng.standard_normal((6000, 3))
+    dd[np.arange(6000), rng.integers(0, 3, 6000)] = 0.0
+    o_list.append(oo); d_list.append(dd)
+    # grazing the unit sphere and along the triangle edge
+    o_list.append(np.array([[1.0, 0.0, -10.0], [0.0, 1.0, -10.0], [0.0, 0.0, 2.0], [-1.0, 0.0, 2.0], [0.0, 0.0, -3.0]]))
+    d_list.append(np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.3, 0.2, 0.1]]))
+    o = np.concatenate(o_list); d = np.concatenate(d_list)
+    for bvh in (0, 1):
+        s = scene_util.SyntheticScene(types, geom, use_bvh=bvh)
+        compare_rays(renderer, s.desc, o, d)
