@@ -828,7 +828,11 @@ Cam make_cam(const rt_camera* c) {
 
 }  // namespace
 
+static uint32_t* g_ray_map = nullptr;  // optional per-pixel Scene::intersect call counts (diagnostics)
+
 extern "C" {
+
+void oracle_set_ray_map(uint32_t* map) { g_ray_map = map; }
 
 // RayTracer::render / renderPathTrace without the PPM write (RayTracer.cpp:206-246, 254-328).
 // rgb: 3*W*H doubles (row 0 = bottom), hit_id: W*H or NULL, counters: {rays, boxes, prims} or NULL.
@@ -853,7 +857,9 @@ int oracle_render(const rt_scene_desc* desc, const rt_camera* cam, const rt_para
                 double v = double(j) / (H - 1);
                 Ray ray = camera_ray(C, u, v, false, nullptr);
                 int first = -1;
+                uint64_t before = c.rays;
                 V3 color = R.trace(ray, 0, c, &first);
+                if (g_ray_map) g_ray_map[(size_t)j * W + i] = (uint32_t)(c.rays - before);
                 color = tone_map(color, P->tonemap);
                 color = color * P->exposure;
                 double* px = rgb + ((size_t)j * W + i) * 3;

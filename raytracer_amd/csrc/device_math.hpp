@@ -77,6 +77,88 @@ RT_DEV bool sphere_t(const double* s, D3 o, D3 d, double& t_out) {
     return true;
 }
 
+// ---- exact division with a shared reciprocal ---------------------------------------------------
+// hipcc expands an f64 a/d into  v_div_scale(d), v_div_scale(a), v_rcp, 2 Newton steps (4 fma),
+// q = a*r, rem = fma(-d, q, a), v_div_fmas(rem, r, q), v_div_fixup  -- 11 instructions, of which the
+// first 6 depend on d only.  When neither operand needs scaling (see ray_regular below) the two
+// v_div_scale are identities, v_div_fmas is a plain fma and v_div_fixup passes its first operand
+// through, so the SAME bits come out of: refine_rcp(d) once, then 3 instructions per quotient.
+// A ray divides dozens of box extents by the same three direction components, which is where
+// BoundingBox::intersect's time goes (6 true divisions per node, BoundingBox.cpp:25-45).
+// tests/test_gpu_rays.py::test_shared_reciprocal_division_is_exact checks the identity on the GPU.
+RT_DEV double refine_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+RT_DEV double div_shared(double a, double d, double r) {
+    double q = a * r;
+    double rem = __builtin_fma(-d, q, a);
+    return __builtin_fma(rem, r, q);
+}
+// |x| == 0 or 2^-300 <= |x| <= 2^300 (false for NaN / inf)
+RT_DEV bool in_window(double x) {
+    double ax = fabs(x);
+    return ax == 0.0 || (ax >= 0x1p-300 && ax <= 0x1p300);
+}
+// A ray for which every slab quotient (box - o)/d stays clear of v_div_scale's scaling cases and
+// of NaN: direction components in [2^-150, 2], origin components 0 or in [2^-300, 2^300].  With box
+// coordinates in the same window (checked on upload) numerators are 0 or >= 2^-353 in magnitude
+// and quotients lie in [2^-354, 2^451].
+RT_DEV bool ray_regular(D3 o, D3 d) {
+    double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    bool dir_ok = ax >= 0x1p-150 && ax <= 2.0 && ay >= 0x1p-150 && ay <= 2.0 && az >= 0x1p-150 && az <= 2.0;
+    return dir_ok && in_window(o.x) && in_window(o.y) && in_window(o.z);
+}
+
+// BoundingBox::intersect for a regular ray.  No NaN can occur, so the reference's swap / early-out
+// sequence reduces exactly to  enter = max of the three slab minima, exit = min of the three slab
+// maxima, hit <=> enter <= exit && exit > 0  (min/max are exact operations).
+RT_DEV bool box_hit_regular(const double* b, D3 o, D3 d, D3 r, double& t_enter) {
+    double x0 = div_shared(b[0] - o.x, d.x, r.x), x1 = div_shared(b[3] - o.x, d.x, r.x);
+    double y0 = div_shared(b[1] - o.y, d.y, r.y), y1 = div_shared(b[4] - o.y, d.y, r.y);
+    double z0 = div_shared(b[2] - o.z, d.z, r.z), z1 = div_shared(b[5] - o.z, d.z, r.z);
+    double enter = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+    double exit = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+    t_enter = enter;
+    return (enter <= exit) && (exit > 0);
+}
+
+// numerator n of a quotient n / (2a) that may use the shared reciprocal of 2a ~ 2
+RT_DEV bool num_ok(double n) {
+    double an = fabs(n);
+    return an == 0.0 || (an >= 0x1p-900 && an <= 0x1p900);
+}
+
+// Sphere::intersect with a = d.d, 2a and refine_rcp(2a) hoisted out (same values every call).
+RT_DEV bool sphere_t_shared(const double* s, D3 o, D3 d, double a, double two_a, double r2a, double& t_out) {
+    D3 oc = o - ld3(s);
+    double b = 2.0 * dot(oc, d);
+    double c = dot(oc, oc) - s[3] * s[3];
+    double disc = b * b - 4 * a * c;
+    if (disc < 0) return false;
+    double sq = sqrt(disc);
+    double n0 = -b - sq, n1 = -b + sq;
+    double t0, t1;
+    if (num_ok(n0) && num_ok(n1)) {
+        t0 = div_shared(n0, two_a, r2a);
+        t1 = div_shared(n1, two_a, r2a);
+    } else {
+        t0 = n0 / two_a;
+        t1 = n1 / two_a;
+    }
+    double t = t0;
+    if (t < 0) {
+        t = t1;
+        if (t < 0) return false;
+    }
+    t_out = t;
+    return true;
+}
+
 // Triangle::intersect (src/Triangle.cpp:42-80), t only; tr = v0, e1 = v1-v0, e2 = v2-v0, n.
 RT_DEV bool triangle_t(const double* tr, D3 o, D3 d, double& t_out) {
     const double EPS = 1e-8;

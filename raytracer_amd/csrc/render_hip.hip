@@ -33,6 +33,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -58,6 +59,12 @@ constexpr int kBlock = 512;          // threads per workgroup
 constexpr int kMaxLdsImage = 150 * 1024;
 constexpr int kNF = 26;              // doubles per frame
 constexpr int kMaxDepthLimit = 64;
+#ifndef RT_TRACE_WAVES_PER_EU
+#define RT_TRACE_WAVES_PER_EU 4
+#endif
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 4  // 128 VGPRs: the walk's live set is small; shading spills a little instead
+#endif
 
 // primitive reference = type << 28 | index within the type's array; -1 = none
 __host__ __device__ inline int make_ref(int type, int idx) { return (type << 28) | idx; }
@@ -87,6 +94,7 @@ struct SceneView {
     int off_ref;                                      // int table: primitive ID -> ref (linear scan)
     int image_bytes;
     int n_lights;
+    int regular;  // every coordinate is 0 or within [2^-300, 2^300]: shared-reciprocal division is exact
     const unsigned char* image;  // global copy of the image
     const DMaterial* materials;
     const int* mat_of_gid;
@@ -145,7 +153,7 @@ RT_DEV bool prim_t(P img, const SceneView& sv, int ref, D3 o, D3 d, double& t, i
 }
 
 template <typename P>
-RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
+RT_DEV HitT closest_hit_ref(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
     HitT best;
     best.ref = -1;
     best.part = 0;
@@ -194,6 +202,112 @@ RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
         }
     }
     return best;
+}
+
+// The same walk for "regular" rays (device_math.hpp: ray_regular), restructured for the SIMD:
+//   * quotients by the three direction components share one refined reciprocal each (3
+//     instructions per exact division instead of 11), and the slab logic is min/max;
+//   * while-while form: every lane walks until IT holds a leaf, then all lanes run the primitive
+//     tests together, instead of every walk step paying for whichever primitive types some lane
+//     happened to reach.
+// Visit order per lane, tie rule and every computed t are those of closest_hit_ref (the parity tests
+// compare the two bit for bit); irregular rays (a zero direction component, ...) take the literal
+// walk.
+template <typename P>
+RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
+    if (!(sv.regular && ray_regular(o, d))) return closest_hit_ref(img, sv, o, d, tally);
+    HitT best;
+    best.ref = -1;
+    best.part = 0;
+    const double a = dot(d, d);  // Sphere.cpp:16, the same value for every sphere of this ray
+    const double two_a = 2.0 * a;
+    const double r2a = refine_rcp(two_a);
+    const double* sph = (const double*)(img + sv.off_sph);
+    const double* tri = (const double*)(img + sv.off_tri);
+    const double* cyl = (const double*)(img + sv.off_cyl);
+    if (sv.n_nodes > 0) {
+        const D3 r = mk(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
+        best.t = __builtin_inf();
+        int i = 0;
+        // node count in a VGPR: as an SGPR the compiler re-loads it from the kernarg segment inside
+        // the walk (s_load + wait on every missed box)
+        int n_nodes;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(n_nodes) : "s"(sv.n_nodes));
+        for (;;) {
+            int p0 = -1, p1 = -1;
+            while (i < n_nodes) {
+                const double* nb = (const double*)(img + sv.off_nodes + i * kNodeBytes);
+                const int* ni = (const int*)(nb + 6);
+                int skip = ni[0], r0 = ni[1], r1 = ni[2];
+                ++tally.box;
+                double t_enter;
+                bool hit = box_hit_regular(nb, o, d, r, t_enter);
+                i = hit ? i + 1 : skip;
+                if (hit && r0 >= 0) {
+                    p0 = r0;
+                    p1 = r1;
+                    break;
+                }
+            }
+            if (p0 < 0) break;
+#pragma unroll 1
+            for (int k = 0; k < 2; ++k) {
+                int ref = k ? p1 : p0;
+                if (ref < 0) break;
+                int type = ref_type(ref), idx = ref_index(ref);
+                double t;
+                int part = 0;
+                bool ok;
+                if (type == RT_SPHERE) {
+                    ++tally.sph;
+                    ok = sphere_t_shared(sph + idx * kSphereDoubles, o, d, a, two_a, r2a, t);
+                } else if (type == RT_TRIANGLE) {
+                    ++tally.tri;
+                    ok = triangle_t(tri + idx * kTriDoubles, o, d, t);
+                } else {
+                    ++tally.cyl;
+                    ok = cylinder_t(cyl + idx * kCylDoubles, o, d, t, part);
+                }
+                if (ok && !(best.t < t)) {
+                    best.t = t;
+                    best.ref = ref;
+                    best.part = part;
+                }
+            }
+        }
+    } else {
+        best.t = 1.7976931348623157e308;
+        const int* refs = (const int*)(img + sv.off_ref);
+        for (int k = 0; k < sv.n_prims; ++k) {
+            int ref = refs[k];
+            int type = ref_type(ref), idx = ref_index(ref);
+            double t;
+            int part = 0;
+            bool ok;
+            if (type == RT_SPHERE) {
+                ++tally.sph;
+                ok = sphere_t_shared(sph + idx * kSphereDoubles, o, d, a, two_a, r2a, t);
+            } else if (type == RT_TRIANGLE) {
+                ++tally.tri;
+                ok = triangle_t(tri + idx * kTriDoubles, o, d, t);
+            } else {
+                ++tally.cyl;
+                ok = cylinder_t(cyl + idx * kCylDoubles, o, d, t, part);
+            }
+            if (ok && t < best.t) {
+                best.t = t;
+                best.ref = ref;
+                best.part = part;
+            }
+        }
+    }
+    return best;
+}
+
+template <bool kFast, typename P>
+RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
+    if (kFast) return closest_hit_fast(img, sv, o, d, tally);
+    return closest_hit_ref(img, sv, o, d, tally);
 }
 
 template <typename P>
@@ -970,8 +1084,9 @@ RT_DEV void advance_path(P img, const SceneView& sv, const RenderArgs& A, const 
 // ------------------------------------------------------------------------------------------------
 // The persistent kernel
 // ------------------------------------------------------------------------------------------------
-template <bool kLds>
-__global__ void __launch_bounds__(kBlock) render_kernel(SceneView sv, RenderArgs A) {
+// kMode: 0 = Whitted / binary, 1 = path trace.  kFast: closest_hit_fast vs the literal walk.
+template <int kMode, bool kLds, bool kFast>
+__global__ void __launch_bounds__(kBlock, RT_WAVES_PER_EU) render_kernel(SceneView sv, RenderArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
     const unsigned char* img;
     if (kLds) {
@@ -1019,7 +1134,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(SceneView sv, RenderArgs
             L.px = px;
             L.lrow = lrow;
             int j = global_row(A, lrow);
-            if (A.mode == RT_MODE_PATHTRACE) {
+            if (kMode == 1) {
                 rng.pixel = (unsigned)((long long)j * A.W + px);
                 F.put3(A.max_depth, 0, mk(0, 0, 0));
                 L.sample = A.s_begin;
@@ -1041,8 +1156,8 @@ __global__ void __launch_bounds__(kBlock) render_kernel(SceneView sv, RenderArgs
 
         if (L.kind != RAY_NONE) {
             ++tally.rays;
-            HitT h = closest_hit(img, sv, L.o, L.d, tally);
-            if (A.mode == RT_MODE_PATHTRACE) advance_path(img, sv, A, F, L, rng, h);
+            HitT h = closest_hit<kFast>(img, sv, L.o, L.d, tally);
+            if (kMode == 1) advance_path(img, sv, A, F, L, rng, h);
             else advance_whitted(img, sv, A, F, L, h);
         }
     }
@@ -1071,16 +1186,18 @@ __global__ void resolve_kernel(double* buf, long long n_pixels, int pixel_sample
     buf[k * 3 + 2] = clamp01(color.z);
 }
 
+#include "wavefront_kernels.inc"
+
 // ---- diagnostics kernels (rt_debug_*) ------------------------------------------------------------
-__global__ void debug_trace_kernel(SceneView sv, long long n, const double* origins, const double* dirs, double* t_out,
-                                   int* prim_out, double* normal_out) {
+__global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const double* origins, const double* dirs,
+                                   double* t_out, int* prim_out, double* normal_out) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const unsigned char* img = sv.image;
     D3 o = ld3(origins + 3 * k);
     D3 d = normalize(ld3(dirs + 3 * k));
     Tally tally = {0, 0, 0, 0, 0};
-    HitT h = closest_hit(img, sv, o, d, tally);
+    HitT h = fast ? closest_hit_fast(img, sv, o, d, tally) : closest_hit_ref(img, sv, o, d, tally);
     if (h.ref >= 0) {
         D3 point, normal;
         hit_geometry(img, sv, h, o, d, point, normal);
@@ -1157,6 +1274,21 @@ struct rt_context {
     int n_bvh_nodes = 0;
     int scene_in_lds = 0;
     int sqrt_spp = 0;
+    bool fast_traversal = true;  // RT_TRAVERSAL=ref selects the literal walk (A/B and parity tests)
+    bool wavefront = true;       // RT_PIPELINE=mega selects the persistent per-pixel kernel
+    unsigned long long generation = 1;  // bumped by upload / set_camera / set_params
+    int n_point_lights = 0, n_area_lights = 0;
+    // wavefront node store
+    double* d_wf_nodes = nullptr;
+    int* d_wf_alive = nullptr;
+    unsigned char* d_wf_shadow = nullptr;
+    void* d_wf_state = nullptr;
+    long long wf_cap = 0;
+    size_t wf_shadow_bytes = 0;
+    unsigned long long wf_calibrated_gen = 0;
+    long long wf_needed_cap = 0;
+    int wf_batch = 1, wf_levels_used = 0;
+    bool last_was_wavefront = false;
 };
 
 namespace {
@@ -1207,6 +1339,8 @@ int upload(T** dst, const std::vector<T>& src) {
     return RT_OK;
 }
 
+#include "wavefront_host.inc"
+
 int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_dev, bool accumulate_only) {
     if (!c->have_scene || !c->have_camera || !c->have_params)
         return rt::set_error(RT_ERR_STATE, "render: scene, camera and params must be set first");
@@ -1250,14 +1384,25 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     A.ticket = c->d_ticket;
     A.counters = c->d_counters;
 
+    c->last_was_wavefront = c->wavefront;
+    if (c->wavefront) {
+        c->scene_in_lds = c->sv.image_bytes <= kMaxLdsImage ? 1 : 0;
+        return launch_wavefront(c, stream, A, accumulate_only);
+    }
+
     // persistent grid: as many workgroups as the chip holds at once
     bool lds = c->sv.image_bytes <= kMaxLdsImage;
     size_t lds_bytes = lds ? (size_t)c->sv.image_bytes : 0;
+    const int kmode = p.mode == RT_MODE_PATHTRACE ? 1 : 0;
+    using KernelFn = void (*)(SceneView, RenderArgs);
+    static const KernelFn table[2][2][2] = {
+        {{render_kernel<0, false, false>, render_kernel<0, false, true>}, {render_kernel<0, true, false>, render_kernel<0, true, true>}},
+        {{render_kernel<1, false, false>, render_kernel<1, false, true>}, {render_kernel<1, true, false>, render_kernel<1, true, true>}}};
+    KernelFn kernel = table[kmode][lds ? 1 : 0][c->fast_traversal ? 1 : 0];
+    if (lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int per_cu = 0;
-    if (lds)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true>, kBlock, lds_bytes));
-    else
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, kBlock, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, kBlock, lds_bytes));
     if (per_cu < 1) per_cu = 1;
     long long want_blocks = (total + kBlock - 1) / kBlock;
     int grid = (int)std::min<long long>((long long)per_cu * c->n_cus, std::max<long long>(want_blocks, 1));
@@ -1281,14 +1426,7 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     HIP_TRY(hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
-    if (lds) {
-        if (lds_bytes > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes));
-        hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, c->sv, A);
-    } else {
-        hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, c->sv, A);
-    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, c->sv, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, stream));
     c->timed = true;
@@ -1323,6 +1461,10 @@ int rt_create(rt_context** out, int device) {
                              prop.gcnArchName);
     rt_context* c = new rt_context();
     c->device = device;
+    const char* trav = std::getenv("RT_TRAVERSAL");
+    c->fast_traversal = !(trav && std::strcmp(trav, "ref") == 0);
+    const char* pipe = std::getenv("RT_PIPELINE");
+    c->wavefront = !(pipe && std::strcmp(pipe, "mega") == 0) && c->fast_traversal;
     c->n_cus = prop.multiProcessorCount;
     std::memset(&c->sv, 0, sizeof c->sv);
     hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
@@ -1343,6 +1485,10 @@ void rt_destroy(rt_context* c) {
     (void)hipDeviceSynchronize();
     free_scene(c);
     (void)hipFree(c->d_frames);
+    (void)hipFree(c->d_wf_nodes);
+    (void)hipFree(c->d_wf_alive);
+    (void)hipFree(c->d_wf_shadow);
+    (void)hipFree(c->d_wf_state);
     (void)hipFree(c->d_ticket);
     (void)hipFree(c->d_counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1406,6 +1552,16 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     std::memset(&sv, 0, sizeof sv);
     sv.n_nodes = bvh.size();
     sv.n_prims = s->n_prims;
+    {
+        auto in_window = [](double x) {
+            double ax = std::fabs(x);
+            return ax == 0.0 || (ax >= 0x1p-300 && ax <= 0x1p300);
+        };
+        bool regular = true;
+        for (double v : bvh.box) regular = regular && in_window(v);
+        for (double v : sph) regular = regular && in_window(v);
+        sv.regular = regular ? 1 : 0;
+    }
     int off = 0;
     sv.off_nodes = off; off = align16(off + sv.n_nodes * kNodeBytes);
     sv.off_sph = off;   off = align16(off + (int)sph.size() * 8);
@@ -1491,6 +1647,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     std::memcpy(sv.bg, s->background, sizeof sv.bg);
     c->sv = sv;
     c->n_bvh_nodes = sv.n_nodes;
+    c->n_point_lights = c->n_area_lights = 0;
+    for (int i = 0; i < s->n_lights; ++i) (s->lights[i].type == RT_LIGHT_POINT ? c->n_point_lights : c->n_area_lights)++;
+    ++c->generation;
     c->have_scene = true;
     c->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
@@ -1499,6 +1658,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
 int rt_set_camera(rt_context* c, const rt_camera* cam) {
     if (!c || !cam) return rt::set_error(RT_ERR_INVALID, "rt_set_camera: null argument");
     c->cam = *cam;
+    ++c->generation;
     c->have_camera = true;
     return RT_OK;
 }
@@ -1517,6 +1677,7 @@ int rt_set_params(rt_context* c, const rt_params* p) {
     if (p->band_rows <= 0 || p->band_world <= 0 || p->band_rank < 0 || p->band_rank >= p->band_world)
         return rt::set_error(RT_ERR_INVALID, "rt_set_params: band partition %d/%d rows %d", p->band_rank, p->band_world, p->band_rows);
     c->params = *p;
+    ++c->generation;
     c->sqrt_spp = 0;
     if (p->mode == RT_MODE_PATHTRACE) {
         if (p->pixel_samples < 0) return rt::set_error(RT_ERR_INVALID, "rt_set_params: pixel_samples %d", p->pixel_samples);
@@ -1600,6 +1761,14 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
         out->triangle_tests = cnt[3];
         out->cylinder_tests = cnt[4];
         out->prim_tests = cnt[2] + cnt[3] + cnt[4];
+        if (c->last_was_wavefront && c->d_wf_state && c->params.max_depth > 0) {
+            WfState st;
+            HIP_TRY(hipMemcpy(&st, c->d_wf_state, sizeof st, hipMemcpyDeviceToHost));
+            if (st.overflow) {
+                c->wf_calibrated_gen = 0;  // recalibrate on the next render
+                return rt::set_error(RT_ERR_LIMIT, "the last render overflowed its node store; its output is invalid, render again");
+            }
+        }
     }
     out->upload_ms = c->upload_ms;
     out->n_bvh_nodes = c->n_bvh_nodes;
@@ -1629,7 +1798,8 @@ int rt_debug_trace_rays(rt_context* c, int64_t n, const double* origins, const d
     if (e == hipSuccess) {
         int block = 256;
         long long grid = (n + block - 1) / block;
-        hipLaunchKernelGGL(debug_trace_kernel, dim3((unsigned)grid), dim3(block), 0, 0, c->sv, (long long)n, d_o, d_d, d_t, d_p, d_n);
+        hipLaunchKernelGGL(debug_trace_kernel, dim3((unsigned)grid), dim3(block), 0, 0, c->sv, c->fast_traversal ? 1 : 0, (long long)n, d_o, d_d,
+                           d_t, d_p, d_n);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(t_out, d_t, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
