@@ -59,6 +59,8 @@ constexpr int kBlock = 512;          // threads per workgroup
 constexpr int kMaxLdsImage = 150 * 1024;
 constexpr int kNF = 26;              // doubles per frame
 constexpr int kMaxDepthLimit = 64;
+constexpr int kCounterSlots = 32768;  // one row of 8 counters per wave: no same-address atomics
+constexpr int kCounterRow = 8;
 #ifndef RT_TRACE_WAVES_PER_EU
 #define RT_TRACE_WAVES_PER_EU 4
 #endif
@@ -140,6 +142,25 @@ struct Tally {
     unsigned rays, box, sph, tri, cyl;
 };
 
+// Adds a wave's tallies to the row this wave owns (rows are per (block, wave); kernels on one
+// stream run one after another, so a plain read-modify-write is enough).  4096 waves doing 5
+// atomics each on the same 5 words cost ~250 us per launch; this costs nothing.
+RT_DEV void flush_tally(const Tally& tally, unsigned long long* counters) {
+    unsigned long long c[5] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl};
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 5; ++k) c[k] += __shfl_down(c[k], off);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (row < (unsigned)kCounterSlots) {
+            unsigned long long* r = counters + (size_t)row * kCounterRow;
+            for (int k = 0; k < 5; ++k) r[k] += c[k];
+        } else {
+            for (int k = 0; k < 5; ++k)
+                if (c[k]) atomicAdd(&counters[k], c[k]);
+        }
+    }
+}
+
 template <typename P>
 RT_DEV bool prim_t(P img, const SceneView& sv, int ref, D3 o, D3 d, double& t, int& part, Tally& tally) {
     int type = ref_type(ref), idx = ref_index(ref);
@@ -213,9 +234,19 @@ RT_DEV HitT closest_hit_ref(P img, const SceneView& sv, D3 o, D3 d, Tally& tally
 // Visit order per lane, tie rule and every computed t are those of closest_hit_ref (the parity tests
 // compare the two bit for bit); irregular rays (a zero direction component, ...) take the literal
 // walk.
-template <typename P>
-RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
-    if (!(sv.regular && ray_regular(o, d))) return closest_hit_ref(img, sv, o, d, tally);
+// kCull: skip nodes that provably cannot hold the winner (entry distance beyond the best t so far,
+//        with the node's safety margin; nodes whose primitives may stick out of their boxes -- the
+//        reference's cylinder boxes assume a +Y axis -- carry an infinite margin and are never culled).
+// kAny:  shadow query "is there a hit with t < t_limit": stops at the first one.  Equivalent to the
+//        reference's "closest hit, then t < lightDistance" (RayTracer.cpp:725-729) because the
+//        closest t is below the limit iff some t is.  Returns ref >= 0 iff occluded.
+template <bool kCull, bool kAny, typename P>
+RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tally, double t_limit = 0.0) {
+    if (!(sv.regular && ray_regular(o, d))) {
+        HitT h = closest_hit_ref(img, sv, o, d, tally);
+        if (kAny && !(h.ref >= 0 && h.t < t_limit)) h.ref = -1;
+        return h;
+    }
     HitT best;
     best.ref = -1;
     best.part = 0;
@@ -242,6 +273,13 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
                 ++tally.box;
                 double t_enter;
                 bool hit = box_hit_regular(nb, o, d, r, t_enter);
+                if (kCull) {
+                    // nothing inside this box can beat `bound`: hits in it have t >= t_enter up to the
+                    // rounding of the primitive tests, which the margin covers many times over
+                    double bound = kAny ? t_limit : best.t;
+                    double margin = (double)__int_as_float(ni[3]) + 1e-4 * fabs(t_enter);
+                    if (t_enter - margin > bound) hit = false;
+                }
                 i = hit ? i + 1 : skip;
                 if (hit && r0 >= 0) {
                     p0 = r0;
@@ -268,7 +306,14 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
                     ++tally.cyl;
                     ok = cylinder_t(cyl + idx * kCylDoubles, o, d, t, part);
                 }
-                if (ok && !(best.t < t)) {
+                if (kAny) {
+                    if (ok && t < t_limit) {
+                        best.t = t;
+                        best.ref = ref;
+                        i = n_nodes;  // occluded: leave the walk
+                        break;
+                    }
+                } else if (ok && !(best.t < t)) {
                     best.t = t;
                     best.ref = ref;
                     best.part = part;
@@ -294,7 +339,13 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
                 ++tally.cyl;
                 ok = cylinder_t(cyl + idx * kCylDoubles, o, d, t, part);
             }
-            if (ok && t < best.t) {
+            if (kAny) {
+                if (ok && t < t_limit) {
+                    best.t = t;
+                    best.ref = ref;
+                    break;
+                }
+            } else if (ok && t < best.t) {
                 best.t = t;
                 best.ref = ref;
                 best.part = part;
@@ -306,7 +357,7 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
 
 template <bool kFast, typename P>
 RT_DEV HitT closest_hit(P img, const SceneView& sv, D3 o, D3 d, Tally& tally) {
-    if (kFast) return closest_hit_fast(img, sv, o, d, tally);
+    if (kFast) return closest_hit_fast<false, false>(img, sv, o, d, tally);
     return closest_hit_ref(img, sv, o, d, tally);
 }
 
@@ -1163,11 +1214,7 @@ __global__ void __launch_bounds__(kBlock, RT_WAVES_PER_EU) render_kernel(SceneVi
     }
 
     // one atomic per wave per counter
-    unsigned long long c[5] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl};
-    for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 5; ++k) c[k] += __shfl_down(c[k], off);
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 5; ++k) atomicAdd(&A.counters[k], c[k]);
+    flush_tally(tally, A.counters);
 }
 
 // RayTracer.cpp:301-315 on a flat buffer
@@ -1197,7 +1244,8 @@ __global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const do
     D3 o = ld3(origins + 3 * k);
     D3 d = normalize(ld3(dirs + 3 * k));
     Tally tally = {0, 0, 0, 0, 0};
-    HitT h = fast ? closest_hit_fast(img, sv, o, d, tally) : closest_hit_ref(img, sv, o, d, tally);
+    HitT h = fast == 2 ? closest_hit_fast<true, false>(img, sv, o, d, tally)
+                       : (fast == 1 ? closest_hit_fast<false, false>(img, sv, o, d, tally) : closest_hit_ref(img, sv, o, d, tally));
     if (h.ref >= 0) {
         D3 point, normal;
         hit_geometry(img, sv, h, o, d, point, normal);
@@ -1233,6 +1281,7 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
             r = rng_u(g, 1, 0);
             break;
         }
+        case 8: r = div_shared(x, y, refine_rcp(y)); break;  // exact division through a shared reciprocal
         default: r = 0.0;
     }
     out[k] = r;
@@ -1274,7 +1323,8 @@ struct rt_context {
     int n_bvh_nodes = 0;
     int scene_in_lds = 0;
     int sqrt_spp = 0;
-    bool fast_traversal = true;  // RT_TRAVERSAL=ref selects the literal walk (A/B and parity tests)
+    bool fast_traversal = true;  // false: RT_TRAVERSAL=ref, the literal walk with true divisions
+    int traversal = 2;           // 0 ref, 1 walk (same visits as the reference), 2 cull (+ any-hit shadows)
     bool wavefront = true;       // RT_PIPELINE=mega selects the persistent per-pixel kernel
     unsigned long long generation = 1;  // bumped by upload / set_camera / set_params
     int n_point_lights = 0, n_area_lights = 0;
@@ -1424,7 +1474,7 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     A.frame_stride = n_threads;
 
     HIP_TRY(hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, (size_t)kCounterSlots * kCounterRow * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, c->sv, A);
     HIP_TRY(hipGetLastError());
@@ -1463,12 +1513,13 @@ int rt_create(rt_context** out, int device) {
     c->device = device;
     const char* trav = std::getenv("RT_TRAVERSAL");
     c->fast_traversal = !(trav && std::strcmp(trav, "ref") == 0);
+    c->traversal = !c->fast_traversal ? 0 : ((trav && std::strcmp(trav, "walk") == 0) ? 1 : 2);
     const char* pipe = std::getenv("RT_PIPELINE");
     c->wavefront = !(pipe && std::strcmp(pipe, "mega") == 0) && c->fast_traversal;
     c->n_cus = prop.multiProcessorCount;
     std::memset(&c->sv, 0, sizeof c->sv);
     hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
-    hipError_t b = hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long));
+    hipError_t b = hipMalloc((void**)&c->d_counters, (size_t)kCounterSlots * kCounterRow * sizeof(unsigned long long));
     hipError_t s0 = hipEventCreate(&c->ev_start);
     hipError_t s1 = hipEventCreate(&c->ev_stop);
     if (a != hipSuccess || b != hipSuccess || s0 != hipSuccess || s1 != hipSuccess) {
@@ -1572,12 +1623,38 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sv.off_gid_cyl = off; off = align16(off + (int)gid_cyl.size() * 4);
     sv.off_ref = off;     off = align16(off + s->n_prims * 4);
     sv.image_bytes = std::max(off, 16);
+    // Culling margin per node (closest_hit_fast<kCull>): absolute slack of 1e-6 of the box's size and
+    // position, or +inf when some primitive below the node is not contained in its reference box
+    // (cylinders whose axis is not exactly +Y, src/Cylinder.cpp:131-137): such nodes are never culled.
+    std::vector<float> cull_margin((size_t)sv.n_nodes, 0.f);
+    {
+        std::vector<char> loose((size_t)sv.n_nodes, 0);
+        auto prim_loose = [&](int gid) {
+            if (gid < 0 || s->prim_type[gid] != RT_CYLINDER) return false;
+            const double* g = s->prim_geom + (size_t)gid * RT_GEOM_STRIDE;
+            H3 ax = h_normalize(g + 3);
+            return !(ax.x == 0.0 && ax.y == 1.0 && ax.z == 0.0);
+        };
+        for (int i = sv.n_nodes - 1; i >= 0; --i) {  // children follow their parent in pre-order
+            bool l = prim_loose(bvh.prim0[i]) || prim_loose(bvh.prim1[i]);
+            if (bvh.right[i] >= 0) l = l || loose[i + 1] || loose[bvh.right[i]];
+            loose[i] = l ? 1 : 0;
+            const double* b = &bvh.box[(size_t)i * 6];
+            double scale = 0.0;
+            for (int k = 0; k < 6; ++k) scale = std::max(scale, std::fabs(b[k]));
+            for (int k = 0; k < 3; ++k) scale += std::fabs(b[3 + k] - b[k]);
+            cull_margin[i] = l ? INFINITY : (float)(1e-6 * scale + 1e-9);
+        }
+    }
     std::vector<unsigned char> image((size_t)sv.image_bytes, 0);
     for (int i = 0; i < sv.n_nodes; ++i) {
         unsigned char* n = image.data() + sv.off_nodes + (size_t)i * kNodeBytes;
         std::memcpy(n, &bvh.box[(size_t)i * 6], 48);
+        float margin = cull_margin[i];
+        int margin_bits;
+        std::memcpy(&margin_bits, &margin, 4);
         int ints[4] = {bvh.skip[i], bvh.prim0[i] >= 0 ? ref_of_gid[bvh.prim0[i]] : -1,
-                       bvh.prim1[i] >= 0 ? ref_of_gid[bvh.prim1[i]] : -1, 0};
+                       bvh.prim1[i] >= 0 ? ref_of_gid[bvh.prim1[i]] : -1, margin_bits};
         std::memcpy(n + 48, ints, 16);
     }
     if (!sph.empty()) std::memcpy(image.data() + sv.off_sph, sph.data(), sph.size() * 8);
@@ -1753,8 +1830,11 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
         out->kernel_ms = ms;
-        unsigned long long cnt[8];
-        HIP_TRY(hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> rows((size_t)kCounterSlots * kCounterRow);
+        HIP_TRY(hipMemcpy(rows.data(), c->d_counters, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t r = 0; r < (size_t)kCounterSlots; ++r)
+            for (int k = 0; k < 5; ++k) cnt[k] += rows[r * kCounterRow + k];
         out->rays = cnt[0];
         out->box_tests = cnt[1];
         out->sphere_tests = cnt[2];
@@ -1798,7 +1878,7 @@ int rt_debug_trace_rays(rt_context* c, int64_t n, const double* origins, const d
     if (e == hipSuccess) {
         int block = 256;
         long long grid = (n + block - 1) / block;
-        hipLaunchKernelGGL(debug_trace_kernel, dim3((unsigned)grid), dim3(block), 0, 0, c->sv, c->fast_traversal ? 1 : 0, (long long)n, d_o, d_d,
+        hipLaunchKernelGGL(debug_trace_kernel, dim3((unsigned)grid), dim3(block), 0, 0, c->sv, c->traversal, (long long)n, d_o, d_d,
                            d_t, d_p, d_n);
         e = hipGetLastError();
     }

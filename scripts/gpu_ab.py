@@ -18,7 +18,7 @@ cases = [("clutter_500", 3840, 2160, 1), ("clutter_500", 1200, 800, 1), ("clutte
          ("binary_primitives", 3840, 2160, 1), ("pathtrace", 480, 270, 1), ("final", 480, 270, 1)]
 ctx = {}
 for mode in ["ref", "fast"]:
-    os.environ["RT_PIPELINE"] = "mega" if mode == "ref" else "wavefront"
+    os.environ["RT_TRAVERSAL"] = "walk" if mode == "ref" else "cull"
     ctx[mode] = rt.Renderer(0)
 for name, w, h, bvh in cases:
     sf = rt.SceneFile(f"scenes/{name}.json", width=w, height=h)
@@ -29,5 +29,5 @@ for name, w, h, bvh in cases:
     for mode in ["ref", "fast"]:
         out[mode] = bench(ctx[mode], sf, desc, P)
     a, b = out["ref"], out["fast"]
-    same = np.array_equal(a[0], b[0]) and (a[1] is None or np.array_equal(a[1], b[1])) and a[2].rays == b[2].rays and a[2].box_tests == b[2].box_tests and a[2].prim_tests == b[2].prim_tests
-    print(f"{name:22s} {w}x{h} bvh={bvh}: rays={b[2].rays} identical={same}  ref {a[3]:.2f} ms ({a[2].rays/a[3]/1e3:.0f} Mrays/s)   fast {b[3]:.2f} ms ({b[2].rays/b[3]/1e3:.0f} Mrays/s)  x{a[3]/b[3]:.2f}", flush=True)
+    same = np.array_equal(a[0], b[0]) and (a[1] is None or np.array_equal(a[1], b[1])) and a[2].rays == b[2].rays
+    print(f"{name:22s} {w}x{h} bvh={bvh}: rays={b[2].rays} identical={same}  ref {a[3]:.2f} ms ({a[2].rays/a[3]/1e3:.0f} Mrays/s)   fast {b[3]:.2f} ms ({b[2].rays/b[3]/1e3:.0f} Mrays/s)  x{a[3]/b[3]:.2f}  box/ray {a[2].box_tests/a[2].rays:.1f}->{b[2].box_tests/b[2].rays:.1f} prim/ray {a[2].prim_tests/a[2].rays:.2f}->{b[2].prim_tests/b[2].rays:.2f}", flush=True)

@@ -1,0 +1,17 @@
+"""Renders one case a few times (for rocprofv3 --kernel-trace)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
+import raytracer_amd as rt
+name, w, h, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+sf = rt.SceneFile(f"scenes/{name}.json", width=w, height=h)
+desc = sf.desc; desc.use_bvh = 1
+P = sf.params
+if P.mode == 2: P.pixel_samples, P.light_samples = 16, 16
+r = rt.Renderer(0)
+r.upload(desc); r.set_camera(sf.camera); r.set_params(P)
+for _ in range(n):
+    r.render(want_hit=False)
+    st = r.stats()
+print(name, st.rays, st.kernel_ms)

@@ -26,6 +26,45 @@ def golden_hits():
     return np.load(os.path.join(GOLDEN, "hit_ids_300x200.npz"))
 
 
+def _make(env):
+    import raytracer_amd as rt
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)  # RT_TRAVERSAL / RT_PIPELINE are read by rt_create
+    try:
+        return rt.Renderer(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="session")
+def renderer_walk():
+    """Wavefront pipeline with the visit-for-visit walk of the reference's BVH (no culling, closest-hit
+    shadow rays): its box / primitive test counts must equal the reference's."""
+    r = _make({"RT_TRAVERSAL": "walk"})
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
+def renderer_mega():
+    """The persistent per-pixel kernel (explicit frame stack), an independent second GPU implementation."""
+    r = _make({"RT_PIPELINE": "mega", "RT_TRAVERSAL": "walk"})
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
+def renderer_literal():
+    """Literal restatement of BVHNode::intersect with true divisions, per-pixel kernel."""
+    r = _make({"RT_TRAVERSAL": "ref"})
+    yield r
+    r.close()
+
+
 @pytest.fixture(scope="session")
 def renderer():
     """One rt_context on cuda:0 for the whole GPU session.  No fallback: fails if the HIP library

@@ -33,11 +33,12 @@ def run_both(renderer, sf, desc=None, params=None):
     return rgb, hit, st, orgb, ohit, cnt
 
 
-def assert_frame_parity(rgb, hit, st, orgb, ohit, cnt, check_hit=True):
+def assert_frame_parity(rgb, hit, st, orgb, ohit, cnt, check_hit=True, check_counts=False):
     if check_hit:
         assert np.array_equal(hit, ohit), f"{(hit != ohit).sum()} primary hit IDs differ"
     assert st.rays == cnt["rays"]
-    assert st.box_tests == cnt["boxes"] and st.prim_tests == cnt["prims"]
+    if check_counts:  # only the visit-for-visit traversal modes make the reference's number of tests
+        assert st.box_tests == cnt["boxes"] and st.prim_tests == cnt["prims"]
     diff = np.abs(rgb - orgb)
     assert diff.max() <= TIGHT_ABS, f"max abs colour difference {diff.max()}"
     assert (diff <= REL_TOL * np.maximum(np.abs(orgb), 1e-12)).all()
@@ -58,6 +59,23 @@ def test_whitted_scenes_300x200(renderer, name, golden_hits):
     key = f"{name}:bvh1"
     if key in golden_hits:
         assert np.array_equal(out[1], golden_hits[key].astype(np.int32))
+
+
+@pytest.mark.parametrize("name", ["clutter_500", "mirror_glass_cylinder", "binary_primitives", "final", "textured"])
+@pytest.mark.parametrize("which", ["walk", "mega", "literal"])
+def test_other_gpu_implementations_agree_and_count_like_the_reference(request, which, name):
+    """The exact-walk wavefront pipeline, the per-pixel kernel and the literal true-division walk are
+    three more GPU implementations: all must give the oracle's frame AND make exactly the reference's
+    number of box and primitive tests (SURVEY.md 8(d) prices the roofline on those counts)."""
+    r = request.getfixturevalue("renderer_" + which)
+    sf = scene_util.load(name, 240, 160)
+    P = sf.params
+    if P.mode == rt.RT_MODE_PATHTRACE:
+        P.mode = rt.RT_MODE_PHONG
+    for bvh in (0, 1):
+        desc = sf.desc
+        desc.use_bvh = bvh
+        assert_frame_parity(*run_both(r, sf, desc=desc, params=P), check_counts=True)
 
 
 @pytest.mark.parametrize("bvh", [0, 1])
@@ -175,6 +193,23 @@ def test_random_soup_with_mirrors_and_glass(renderer, seed):
         st = renderer.stats()
         orgb, ohit, cnt, _ = oracle_lib.render(s.desc, cam, P)
         assert_frame_parity(rgb, hit, st, orgb, ohit, cnt)
+
+
+def test_culling_never_changes_a_hit_on_loose_cylinder_boxes(renderer, renderer_walk):
+    """Cylinders with arbitrary axes stick out of the boxes the reference gives them
+    (src/Cylinder.cpp:131-137); nodes above them must never be culled by entry distance."""
+    rng = np.random.default_rng(77)
+    types, geom = scene_util.random_prims(rng, 10, 10, 60)
+    o = rng.uniform(-7, 7, (300_000, 3))
+    d = rng.standard_normal((300_000, 3))
+    s = scene_util.SyntheticScene(types, geom, use_bvh=1)
+    renderer.upload(s.desc)
+    renderer_walk.upload(s.desc)
+    a = renderer.trace_rays(o, d)
+    b = renderer_walk.trace_rays(o, d)
+    ot, oprim, onrm = oracle_lib.trace_rays(s.desc, o, d)
+    for got in (a, b):
+        assert np.array_equal(got[1], oprim) and np.array_equal(got[0], ot) and np.array_equal(got[2], onrm)
 
 
 def test_band_partition_reassembles_bit_exactly(renderer):

@@ -33,6 +33,25 @@ def test_division_and_sqrt_are_correctly_rounded(renderer):
     assert np.array_equal(renderer.math(1, x), np.sqrt(x))
 
 
+def test_shared_reciprocal_division_is_exact(renderer):
+    """device_math.hpp div_shared: op 8 evaluates a / d through refine_rcp(d) + 3 instructions; inside
+    the window ray_regular() guarantees it must equal the IEEE quotient bit for bit, including
+    mantissas of all ones and numerators of 0."""
+    rng = np.random.default_rng(13)
+    n = 6_000_000
+    a = rng.standard_normal(n) * np.exp2(rng.uniform(-350, 300, n))
+    d = np.copysign(np.exp2(rng.uniform(-150, 1, n)), rng.standard_normal(n))
+    d = np.clip(np.abs(d), 2.0 ** -150, 2.0) * np.sign(d)
+    # adversarial mantissas
+    m = 200_000
+    ones = np.frombuffer((np.uint64(0x3FEFFFFFFFFFFFFF) - rng.integers(0, 4, m).astype(np.uint64)).tobytes(), dtype=np.float64)
+    d[:m] = ones * np.exp2(rng.integers(-149, 1, m).astype(np.float64))
+    a[m:2 * m] = np.frombuffer((np.uint64(0x3FF0000000000000) + rng.integers(0, 4, m).astype(np.uint64)).tobytes(), dtype=np.float64)
+    a[2 * m:2 * m + 1000] = 0.0
+    got = renderer.math(8, a, d)
+    assert np.array_equal(got, a / d)
+
+
 def test_transcendentals_within_a_few_ulp(renderer):
     """pow/atan2/acos/cos/sin of the device library are not bit-identical to glibc; the contract only
     needs colours within 1e-4.  Measured: <= 2 ulp."""
