@@ -78,6 +78,12 @@ def main():
         desc.use_bvh = 1
     W, H = base.width, base.height
 
+    # Reference-order work of one frame: the roofline's numerator is counted on the
+    # reference's own traversal, so one untimed frame is rendered with the visit-for-visit walk
+    # (RT_TRAVERSAL=walk) on this rank's share, before the production context is created.
+    os.environ["RT_TRAVERSAL"] = "walk"
+    rw = rt.Renderer(local_rank)
+    os.environ.pop("RT_TRAVERSAL")
     r = rt.Renderer(local_rank)
     r.upload(desc)
     r.set_camera(sf.camera)
@@ -92,6 +98,13 @@ def main():
         P.band_rank, P.band_world = rank, world
     r.set_params(P)
     rows = r.local_rows
+    rw.upload(desc)
+    rw.set_camera(sf.camera)
+    rw.set_params(P)
+    rw.render(want_hit=False)
+    ref_st = rw.stats()
+    ref_counts = [ref_st.rays, ref_st.box_tests, ref_st.sphere_tests, ref_st.triangle_tests, ref_st.cylinder_tests]
+    rw.close()
     stream = torch.cuda.current_stream().cuda_stream
 
     if pathtrace:
@@ -153,12 +166,14 @@ def main():
     st = r.stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([st.rays, st.box_tests, st.sphere_tests, st.triangle_tests, st.cylinder_tests],
-                       dtype=torch.float64, device=dev)
+    assert st.rays == ref_counts[0], "the production traversal must trace exactly the reference's rays"
+    cnt = torch.tensor(ref_counts, dtype=torch.float64, device=dev)
+    done = torch.tensor([st.box_tests, st.prim_tests], dtype=torch.float64, device=dev)
     kms = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(done, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     rays, boxes, sph, tri, cyl = (float(x) for x in cnt.tolist())
@@ -183,8 +198,11 @@ def main():
                        "parallelism": ("strata-range x%d + RCCL reduce" if pathtrace else "row-band x%d + RCCL gather") % world},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VALU_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
-                         "kernel": "render_kernel<LDS>", "kernel_ms": k_ms,
+                         "kernel": "wavefront frame (raygen + per depth: trace, shadow, shade; combine; resolve)", "kernel_ms": k_ms,
                          "ops_per_ray": alg_ops / max(rays, 1.0),
+                         "reference_box_tests_per_ray": boxes / max(rays, 1.0),
+                         "executed_box_tests_per_ray": float(done[0].item()) / max(rays, 1.0),
+                         "executed_prim_tests_per_ray": float(done[1].item()) / max(rays, 1.0),
                          "note": "fp64 ops without FMA credit (contraction off for parity); peak = 78.6/2"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "libraytracer_amd.so")  # RT_AMD_LIB: A/B builds
 
 RT_GEOM_STRIDE = 12
 RT_SPHERE, RT_TRIANGLE, RT_CYLINDER = 0, 1, 2

@@ -55,7 +55,8 @@ constexpr int kNodeBytes = 64;  // 6 doubles box, int skip, int ref0, int ref1, 
 constexpr int kSphereDoubles = 4;
 constexpr int kTriDoubles = 12;
 constexpr int kCylDoubles = 8;
-constexpr int kBlock = 512;          // threads per workgroup
+constexpr int kBlock = 512;          // threads per workgroup (per-pixel kernel)
+constexpr int kTraceBlock = 1024;    // wavefront trace kernels: one LDS scene image per 16 waves
 constexpr int kMaxLdsImage = 150 * 1024;
 constexpr int kNF = 26;              // doubles per frame
 constexpr int kMaxDepthLimit = 64;
@@ -97,6 +98,9 @@ struct SceneView {
     int image_bytes;
     int n_lights;
     int regular;  // every coordinate is 0 or within [2^-300, 2^300]: shared-reciprocal division is exact
+    int fbvh_ok, n_fnodes;                       // filter BVH present (fbvh_build.cpp)
+    int off_fnodes, off_flinks, off_leafprim;     // 32 B nodes, [node][octant] int2 links, int4 leaf records
+    double scene_scale;
     const unsigned char* image;  // global copy of the image
     const DMaterial* materials;
     const int* mat_of_gid;
@@ -353,6 +357,114 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
         }
     }
     return best;
+}
+
+// ---- filter-BVH traversal (fbvh_build.cpp explains why this returns the reference's answer) ------
+// Inner loop: fp32 conservative slab test on an enlarged box, children in near-to-far order for the
+// ray's octant through precomputed links (no stack), culled against the best t so far.  Leaves: the
+// reference's own two fp64 tests -- the gate box (BoundingBox::intersect on the BVHNode that holds
+// the primitive) and the primitive -- and the reference's tie rule via the DFS-order key.
+template <bool kAny, typename P>
+RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tally, double t_limit = 0.0) {
+    const double reach = 4.0 * sv.scene_scale;
+    bool eligible = sv.fbvh_ok && sv.regular && ray_regular(o, d) && fabs(d.x) >= 0x1p-60 && fabs(d.y) >= 0x1p-60 &&
+                    fabs(d.z) >= 0x1p-60 && fabs(o.x) <= reach && fabs(o.y) <= reach && fabs(o.z) <= reach;
+    if (!eligible) return closest_hit_fast<false, kAny>(img, sv, o, d, tally, t_limit);
+    const double a = dot(d, d);
+    const double two_a = 2.0 * a;
+    const double r2a = refine_rcp(two_a);
+    const D3 r = mk(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
+    const float ofx = (float)o.x, ofy = (float)o.y, ofz = (float)o.z;
+    const float rix = (float)r.x, riy = (float)r.y, riz = (float)r.z;
+    const int oct = (d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0);
+    const double* sph = (const double*)(img + sv.off_sph);
+    const double* tri = (const double*)(img + sv.off_tri);
+    const double* cyl = (const double*)(img + sv.off_cyl);
+    HitT best;
+    best.ref = -1;
+    best.part = 0;
+    best.t = kAny ? t_limit : __builtin_inf();
+    int best_key = -2147483647 - 1;
+    float bound = kAny ? (float)(t_limit * 1.00003) : __builtin_inff();
+    const float kSlack = 2e-5f;  // fp32 rounding (1e-6) + hit points displaced along the ray (1e-5 t)
+    int i = 0;
+    for (;;) {
+        int lf = 0, lc = 0;
+        while (i >= 0) {
+            const float4* fb = (const float4*)(img + sv.off_fnodes + i * 32);
+            float4 b0 = fb[0], b1 = fb[1];  // lo.x lo.y lo.z hi.x | hi.y hi.z first count
+            int2 lk = *(const int2*)(img + sv.off_flinks + (i * 8 + oct) * 8);
+            ++tally.box;
+            float x0 = (b0.x - ofx) * rix, x1 = (b0.w - ofx) * rix;
+            float y0 = (b0.y - ofy) * riy, y1 = (b1.x - ofy) * riy;
+            float z0 = (b0.z - ofz) * riz, z1 = (b1.y - ofz) * riz;
+            float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+            float exit = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            float enter_lo = enter - kSlack * fabsf(enter);
+            float exit_hi = exit + kSlack * fabsf(exit);
+            bool pass = (enter_lo <= exit_hi) && (exit_hi >= 0.f) && (enter_lo <= bound);
+            int cnt = __float_as_int(b1.w);
+            i = pass ? lk.x : lk.y;
+            if (pass && cnt > 0) {
+                lf = __float_as_int(b1.z);
+                lc = cnt;
+                break;
+            }
+        }
+        if (lc == 0) break;
+#pragma unroll 1
+        for (int k = 0; k < lc; ++k) {
+            int4 lp = *(const int4*)(img + sv.off_leafprim + (lf + k) * 16);  // ref, gate, key
+            if (lp.y >= 0) {
+                const double* nb = (const double*)(img + sv.off_nodes + lp.y * kNodeBytes);
+                double t_enter;
+                ++tally.box;
+                if (!box_hit_regular(nb, o, d, r, t_enter)) continue;
+            }
+            int ref = lp.x;
+            int type = ref_type(ref), idx = ref_index(ref);
+            double t;
+            int part = 0;
+            bool ok;
+            if (type == RT_SPHERE) {
+                ++tally.sph;
+                ok = sphere_t_shared(sph + idx * kSphereDoubles, o, d, a, two_a, r2a, t);
+            } else if (type == RT_TRIANGLE) {
+                ++tally.tri;
+                ok = triangle_t(tri + idx * kTriDoubles, o, d, t);
+            } else {
+                ++tally.cyl;
+                ok = cylinder_t(cyl + idx * kCylDoubles, o, d, t, part);
+            }
+            if (!ok) continue;
+            if (kAny) {
+                if (t < t_limit) {
+                    best.t = t;
+                    best.ref = ref;
+                    i = -1;  // occluded: leave the walk
+                    break;
+                }
+            } else if (t < best.t || (t == best.t && lp.z > best_key)) {
+                best.t = t;
+                best.ref = ref;
+                best.part = part;
+                best_key = lp.z;
+                bound = (float)(t * 1.00003);
+            }
+        }
+    }
+    if (kAny && best.ref < 0) best.t = 0.0;
+    return best;
+}
+
+// kTrav: 1 = visit-for-visit walk of the reference tree, 2 = + culling / any-hit, 3 = filter BVH
+template <int kTrav, bool kAny, typename P>
+RT_DEV HitT trace_ray(P img, const SceneView& sv, D3 o, D3 d, Tally& tally, double t_limit = 0.0) {
+    if (kTrav == 3) return closest_hit_fbvh<kAny>(img, sv, o, d, tally, t_limit);
+    if (kTrav == 2) return closest_hit_fast<true, kAny>(img, sv, o, d, tally, t_limit);
+    HitT h = closest_hit_fast<false, false>(img, sv, o, d, tally);
+    if (kAny && !(h.ref >= 0 && h.t < t_limit)) h.ref = -1;
+    return h;
 }
 
 template <bool kFast, typename P>
@@ -1234,6 +1346,7 @@ __global__ void resolve_kernel(double* buf, long long n_pixels, int pixel_sample
 }
 
 #include "wavefront_kernels.inc"
+#include "blockwave_kernels.inc"
 
 // ---- diagnostics kernels (rt_debug_*) ------------------------------------------------------------
 __global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const double* origins, const double* dirs,
@@ -1244,7 +1357,8 @@ __global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const do
     D3 o = ld3(origins + 3 * k);
     D3 d = normalize(ld3(dirs + 3 * k));
     Tally tally = {0, 0, 0, 0, 0};
-    HitT h = fast == 2 ? closest_hit_fast<true, false>(img, sv, o, d, tally)
+    HitT h = fast == 3 ? closest_hit_fbvh<false>(img, sv, o, d, tally)
+           : fast == 2 ? closest_hit_fast<true, false>(img, sv, o, d, tally)
                        : (fast == 1 ? closest_hit_fast<false, false>(img, sv, o, d, tally) : closest_hit_ref(img, sv, o, d, tally));
     if (h.ref >= 0) {
         D3 point, normal;
@@ -1324,8 +1438,11 @@ struct rt_context {
     int scene_in_lds = 0;
     int sqrt_spp = 0;
     bool fast_traversal = true;  // false: RT_TRAVERSAL=ref, the literal walk with true divisions
-    int traversal = 2;           // 0 ref, 1 walk (same visits as the reference), 2 cull (+ any-hit shadows)
+    int traversal = 3;           // 0 ref, 1 walk (same visits as the reference), 2 cull (+ any-hit shadows), 3 filter BVH
     bool wavefront = true;       // RT_PIPELINE=mega selects the persistent per-pixel kernel
+    bool level_kernels = false;  // RT_PIPELINE=levels: one kernel per phase and depth instead of one per frame
+    unsigned* d_bw_info = nullptr;
+    int bw_info_blocks = 0;
     unsigned long long generation = 1;  // bumped by upload / set_camera / set_params
     int n_point_lights = 0, n_area_lights = 0;
     // wavefront node store
@@ -1390,6 +1507,7 @@ int upload(T** dst, const std::vector<T>& src) {
 }
 
 #include "wavefront_host.inc"
+#include "blockwave_host.inc"
 
 int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_dev, bool accumulate_only) {
     if (!c->have_scene || !c->have_camera || !c->have_params)
@@ -1437,7 +1555,7 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     c->last_was_wavefront = c->wavefront;
     if (c->wavefront) {
         c->scene_in_lds = c->sv.image_bytes <= kMaxLdsImage ? 1 : 0;
-        return launch_wavefront(c, stream, A, accumulate_only);
+        return c->level_kernels ? launch_wavefront(c, stream, A, accumulate_only) : launch_blockwave(c, stream, A, accumulate_only);
     }
 
     // persistent grid: as many workgroups as the chip holds at once
@@ -1513,9 +1631,10 @@ int rt_create(rt_context** out, int device) {
     c->device = device;
     const char* trav = std::getenv("RT_TRAVERSAL");
     c->fast_traversal = !(trav && std::strcmp(trav, "ref") == 0);
-    c->traversal = !c->fast_traversal ? 0 : ((trav && std::strcmp(trav, "walk") == 0) ? 1 : 2);
+    c->traversal = !c->fast_traversal ? 0 : ((trav && std::strcmp(trav, "walk") == 0) ? 1 : ((trav && std::strcmp(trav, "cull") == 0) ? 2 : 3));
     const char* pipe = std::getenv("RT_PIPELINE");
     c->wavefront = !(pipe && std::strcmp(pipe, "mega") == 0) && c->fast_traversal;
+    c->level_kernels = pipe && std::strcmp(pipe, "levels") == 0;
     c->n_cus = prop.multiProcessorCount;
     std::memset(&c->sv, 0, sizeof c->sv);
     hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
@@ -1540,6 +1659,7 @@ void rt_destroy(rt_context* c) {
     (void)hipFree(c->d_wf_alive);
     (void)hipFree(c->d_wf_shadow);
     (void)hipFree(c->d_wf_state);
+    (void)hipFree(c->d_bw_info);
     (void)hipFree(c->d_ticket);
     (void)hipFree(c->d_counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1622,6 +1742,16 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sv.off_gid_tri = off; off = align16(off + (int)gid_tri.size() * 4);
     sv.off_gid_cyl = off; off = align16(off + (int)gid_cyl.size() * 4);
     sv.off_ref = off;     off = align16(off + s->n_prims * 4);
+    rt::FilterBVH fb;
+    rt::build_filter_bvh(s, s->use_bvh ? &bvh : nullptr, fb);
+    sv.fbvh_ok = fb.ok ? 1 : 0;
+    sv.n_fnodes = fb.n_nodes;
+    sv.scene_scale = fb.scene_scale;
+    if (fb.ok) {
+        sv.off_fnodes = off;   off = align16(off + fb.n_nodes * 32);
+        sv.off_flinks = off;   off = align16(off + fb.n_nodes * 64);
+        sv.off_leafprim = off; off = align16(off + s->n_prims * 16);
+    }
     sv.image_bytes = std::max(off, 16);
     // Culling margin per node (closest_hit_fast<kCull>): absolute slack of 1e-6 of the box's size and
     // position, or +inf when some primitive below the node is not contained in its reference box
@@ -1664,6 +1794,19 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (!gid_tri.empty()) std::memcpy(image.data() + sv.off_gid_tri, gid_tri.data(), gid_tri.size() * 4);
     if (!gid_cyl.empty()) std::memcpy(image.data() + sv.off_gid_cyl, gid_cyl.data(), gid_cyl.size() * 4);
     if (s->n_prims) std::memcpy(image.data() + sv.off_ref, ref_of_gid.data(), (size_t)s->n_prims * 4);
+    if (fb.ok) {
+        for (int i = 0; i < fb.n_nodes; ++i) {
+            unsigned char* n = image.data() + sv.off_fnodes + (size_t)i * 32;
+            std::memcpy(n, &fb.box[(size_t)i * 6], 24);
+            std::memcpy(n + 24, &fb.leaf_first[i], 4);
+            std::memcpy(n + 28, &fb.leaf_count[i], 4);
+        }
+        std::memcpy(image.data() + sv.off_flinks, fb.links.data(), fb.links.size() * 4);
+        for (int k = 0; k < s->n_prims; ++k) {
+            int rec[4] = {ref_of_gid[fb.leaf_prim[(size_t)k * 4]], fb.leaf_prim[(size_t)k * 4 + 1], fb.leaf_prim[(size_t)k * 4 + 2], 0};
+            std::memcpy(image.data() + sv.off_leafprim + (size_t)k * 16, rec, 16);
+        }
+    }
 
     std::vector<DMaterial> mats(s->n_materials);
     for (int i = 0; i < s->n_materials; ++i) {
@@ -1842,9 +1985,15 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
         out->cylinder_tests = cnt[4];
         out->prim_tests = cnt[2] + cnt[3] + cnt[4];
         if (c->last_was_wavefront && c->d_wf_state && c->params.max_depth > 0) {
-            WfState st;
-            HIP_TRY(hipMemcpy(&st, c->d_wf_state, sizeof st, hipMemcpyDeviceToHost));
-            if (st.overflow) {
+            unsigned overflow = 0;
+            if (c->level_kernels) {
+                WfState st;
+                HIP_TRY(hipMemcpy(&st, c->d_wf_state, sizeof st, hipMemcpyDeviceToHost));
+                overflow = st.overflow;
+            } else {
+                HIP_TRY(hipMemcpy(&overflow, c->d_wf_state, sizeof overflow, hipMemcpyDeviceToHost));
+            }
+            if (overflow) {
                 c->wf_calibrated_gen = 0;  // recalibrate on the next render
                 return rt::set_error(RT_ERR_LIMIT, "the last render overflowed its node store; its output is invalid, render again");
             }

@@ -33,6 +33,20 @@ struct FlatBVH {
 // the same comparison sequence, same span/2 split).
 void build_flat_bvh(const rt_scene_desc* scene, FlatBVH& out);
 
+// Device-side acceleration structure (fbvh_build.cpp): SAH binary BVH over true primitive bounds,
+// fp32 boxes, per-octant hit/miss links, leaves carrying (primitive, gate, tie key).
+struct FilterBVH {
+    bool ok = false;
+    int n_nodes = 0;
+    double scene_scale = 0.0;          // max |coordinate| of the primitives' true bounds
+    std::vector<float> box;            // [n][6] lo xyz, hi xyz (already enlarged, rounded outward)
+    std::vector<int32_t> leaf_first;   // [n] first record in leaf_prim (leaves), 0 otherwise
+    std::vector<int32_t> leaf_count;   // [n] number of records (0 for inner nodes)
+    std::vector<int32_t> links;        // [n][8 octants][2]: next node when the box passes / fails; -1 = done
+    std::vector<int32_t> leaf_prim;    // [n_prims][4]: primitive ID, gate = reference node index or -1, tie key, 0
+};
+void build_filter_bvh(const rt_scene_desc* scene, const FlatBVH* ref_bvh, FilterBVH& out);
+
 // Per-primitive AABBs as the reference's getBoundingBox() returns them, including the
 // cylinder box that assumes a +Y axis (src/Cylinder.cpp:131-137).
 void prim_bounds(const rt_scene_desc* scene, int prim, double box[6]);

@@ -50,6 +50,14 @@ def renderer_walk():
 
 
 @pytest.fixture(scope="session")
+def renderer_levels():
+    """The same level-synchronous evaluation as grid-wide kernels (one per phase and depth)."""
+    r = _make({"RT_PIPELINE": "levels"})
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
 def renderer_mega():
     """The persistent per-pixel kernel (explicit frame stack), an independent second GPU implementation."""
     r = _make({"RT_PIPELINE": "mega", "RT_TRAVERSAL": "walk"})

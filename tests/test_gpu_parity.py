@@ -61,6 +61,15 @@ def test_whitted_scenes_300x200(renderer, name, golden_hits):
         assert np.array_equal(out[1], golden_hits[key].astype(np.int32))
 
 
+@pytest.mark.parametrize("name", ["clutter_500", "mirror_glass_cylinder", "final", "textured"])
+def test_level_kernel_pipeline_agrees(renderer_levels, name):
+    sf = scene_util.load(name, 240, 160)
+    P = sf.params
+    if P.mode == rt.RT_MODE_PATHTRACE:
+        P.mode = rt.RT_MODE_PHONG
+    assert_frame_parity(*run_both(renderer_levels, sf, params=P))
+
+
 @pytest.mark.parametrize("name", ["clutter_500", "mirror_glass_cylinder", "binary_primitives", "final", "textured"])
 @pytest.mark.parametrize("which", ["walk", "mega", "literal"])
 def test_other_gpu_implementations_agree_and_count_like_the_reference(request, which, name):

@@ -50,6 +50,33 @@ def test_same_rng_same_image(renderer, name, spp, ls):
     assert_pt_parity(*gpu_and_oracle(renderer, sf, P))
 
 
+@pytest.mark.parametrize("which", ["levels", "mega"])
+def test_other_pipelines_path_trace_the_same_image(request, which):
+    r = request.getfixturevalue("renderer_" + which)
+    sf = scene_util.load("final", 120, 80)
+    P = sf.params
+    P.pixel_samples, P.light_samples = 4, 3
+    assert_pt_parity(*gpu_and_oracle(r, sf, P))
+
+
+def test_many_strata_in_several_passes(renderer, monkeypatch):
+    """A node budget small enough to force several passes over the strata: sums must not change."""
+    sf = scene_util.load("pathtrace", 64, 48)
+    P = sf.params
+    P.pixel_samples, P.light_samples = 36, 2
+    renderer.load(sf, P)
+    a, _ = renderer.render(want_hit=False)
+    monkeypatch.setenv("RT_WF_NODE_BUDGET", "70000")
+    P.seed = 1
+    renderer.set_params(P)   # new generation -> re-plan with the small budget
+    P.seed = 0
+    renderer.set_params(P)
+    b, _ = renderer.render(want_hit=False)
+    assert np.array_equal(a, b)
+    orgb, _, _, _ = oracle_lib.render(sf.desc, sf.camera, P, want_hit=False)
+    assert (np.abs(b - orgb).max(axis=2) > 1e-9).mean() <= 1e-3
+
+
 def test_non_square_sample_count_darkens_like_the_reference(renderer):
     # pixelSamples = 10 -> 3x3 strata but divided by 10 (RayTracer.cpp:255, 301)
     sf = scene_util.load("pathtrace", 90, 60)
