@@ -54,6 +54,7 @@ def main():
     import torch.distributed as dist
 
     import raytracer_amd as rt
+    from raytracer_amd import dist as rtd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,11 +90,7 @@ def main():
     r.set_camera(sf.camera)
     P = rt.copy_params(base)
     if pathtrace:
-        n_strata = base.pixel_samples
-        lo = (n_strata * rank) // world
-        hi = (n_strata * (rank + 1)) // world
-        # an empty share (more ranks than strata) is the range [n, n): sample_end <= 0 would mean "all"
-        P.sample_begin, P.sample_end = (lo, hi) if hi > lo else (n_strata, n_strata)
+        P.sample_begin, P.sample_end = rtd.strata_range(rank, world, base.pixel_samples)
     else:
         P.band_rank, P.band_world = rank, world
     r.set_params(P)
@@ -109,38 +106,18 @@ def main():
 
     if pathtrace:
         accum = torch.empty(H * W * 3, dtype=torch.float64, device=dev)
-        out = accum
     else:
-        # equal-sized gather slots: every rank's compact band buffer padded to the largest
-        band = P.band_rows
-        n_bands = (H + band - 1) // band
-        max_rows = ((n_bands + world - 1) // world) * band
-        mine = torch.zeros(max_rows * W * 3, dtype=torch.float64, device=dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)] if (world > 1 and rank == 0) else None
-        frame = torch.empty(H, W, 3, dtype=torch.float64, device=dev) if rank == 0 else None
-        row_index = None
-        if world > 1 and rank == 0:
-            # destination rows of rank q's compact rows, for the scatter into the frame
-            row_index = []
-            for q in range(world):
-                rws = [j for b in range(q, n_bands, world) for j in range(b * band, min(H, (b + 1) * band))]
-                row_index.append(torch.tensor(rws, dtype=torch.long, device=dev))
+        gatherer = rtd.BandGatherer(rank, world, H, W, dev, band_rows=P.band_rows)
 
     def step():
         if pathtrace:
             r.accumulate_device(accum.data_ptr(), stream=stream)
-            if world > 1:
-                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            rtd.reduce_accumulators(accum, world)
             if rank == 0:
                 r.resolve_device(accum.data_ptr(), H * W, stream=stream)
         else:
-            r.render_device(mine.data_ptr(), None, stream=stream)
-            if world > 1:
-                dist.gather(mine, gathered, dst=0)
-                if rank == 0:
-                    for q in range(world):
-                        n = row_index[q].numel()
-                        frame.index_copy_(0, row_index[q], gathered[q][: n * W * 3].view(n, W, 3))
+            r.render_device(gatherer.mine.data_ptr(), None, stream=stream)
+            gatherer.gather()
 
     def sync_all():
         torch.cuda.synchronize()

@@ -1,0 +1,64 @@
+"""Partition of one frame over ranks and its recombination with torch.distributed.
+
+Whitted / binary: 8-row bands dealt round-robin (rt_params.band_*), disjoint outputs -> gather.
+Path trace: strata ranges (rt_params.sample_begin/sample_end), partial radiance sums -> reduce(SUM)
+BEFORE the non-linear stages (division by pixelSamples, tone map, exposure, gamma, clamp:
+/root/reference/src/RayTracer.cpp:301-315).  The same functions run over RCCL on GPUs (bench.py)
+and over gloo on CPU tensors (tests/test_multiproc_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def band_rows_of(rank, world, height, band_rows=8):
+    """Global row indices (bottom row = 0) a rank renders, in the order of its compact buffer."""
+    n_bands = (height + band_rows - 1) // band_rows
+    return [j for b in range(rank, n_bands, world) for j in range(b * band_rows, min(height, (b + 1) * band_rows))]
+
+
+def max_band_rows(world, height, band_rows=8):
+    n_bands = (height + band_rows - 1) // band_rows
+    return ((n_bands + world - 1) // world) * band_rows
+
+
+def strata_range(rank, world, n_strata):
+    """[begin, end) of the strata a rank accumulates; an empty share is (n, n) because
+    sample_end <= 0 means "all" in rt_params."""
+    lo, hi = (n_strata * rank) // world, (n_strata * (rank + 1)) // world
+    return (lo, hi) if hi > lo else (n_strata, n_strata)
+
+
+class BandGatherer:
+    """Gathers every rank's compact band buffer on rank 0 and scatters the rows into the frame."""
+
+    def __init__(self, rank, world, height, width, device, band_rows=8, dtype=torch.float64, channels=3):
+        self.rank, self.world, self.H, self.W, self.C = rank, world, height, width, channels
+        self.slot_rows = max_band_rows(world, height, band_rows)
+        self.mine = torch.zeros(self.slot_rows * width * channels, dtype=dtype, device=device)
+        self.frame = torch.empty(height, width, channels, dtype=dtype, device=device) if rank == 0 else None
+        self.slots = [torch.empty_like(self.mine) for _ in range(world)] if (rank == 0 and world > 1) else None
+        self.index = None
+        if rank == 0:
+            self.index = [torch.tensor(band_rows_of(q, world, height, band_rows), dtype=torch.long, device=device)
+                          for q in range(world)]
+
+    def gather(self):
+        """self.mine must hold this rank's rows.  Returns the frame on rank 0, None elsewhere."""
+        if self.world == 1:
+            n = self.index[0].numel()
+            self.frame.index_copy_(0, self.index[0], self.mine[: n * self.W * self.C].view(n, self.W, self.C))
+            return self.frame
+        dist.gather(self.mine, self.slots, dst=0)
+        if self.rank != 0:
+            return None
+        for q in range(self.world):
+            n = self.index[q].numel()
+            self.frame.index_copy_(0, self.index[q], self.slots[q][: n * self.W * self.C].view(n, self.W, self.C))
+        return self.frame
+
+
+def reduce_accumulators(accum, world):
+    """Sum of the per-rank radiance accumulators on rank 0 (in place)."""
+    if world > 1:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    return accum
