@@ -52,6 +52,7 @@ using namespace rtd;
 namespace {
 
 constexpr int kNodeBytes = 64;  // 6 doubles box, int skip, int ref0, int ref1, int pad
+constexpr int kFNodeBytes = 96;  // filter BVH: 6 floats box, leaf first, leaf count, 8 x (pass, fail) links as image offsets
 constexpr int kSphereDoubles = 4;
 constexpr int kTriDoubles = 12;
 constexpr int kCylDoubles = 8;
@@ -99,7 +100,7 @@ struct SceneView {
     int n_lights;
     int regular;  // every coordinate is 0 or within [2^-300, 2^300]: shared-reciprocal division is exact
     int fbvh_ok, n_fnodes;                       // filter BVH present (fbvh_build.cpp)
-    int off_fnodes, off_flinks, off_leafprim;     // 32 B nodes, [node][octant] int2 links, int4 leaf records
+    int off_fnodes, off_leafprim;                // 96 B nodes (box, leaf range, [octant] int2 links), int4 leaf records
     double scene_scale;
     const unsigned char* image;  // global copy of the image
     const DMaterial* materials;
@@ -374,9 +375,12 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
     const double two_a = 2.0 * a;
     const double r2a = refine_rcp(two_a);
     const D3 r = mk(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
-    const float ofx = (float)o.x, ofy = (float)o.y, ofz = (float)o.z;
+    // fp32 slab test as one FMA per plane: t = b * (1/d) - o * (1/d).  Error in position space is
+    // (|b| + |o|) 2^-24 <= 5 S 2^-24 = 3e-7 S, inside the 2^-20 S the boxes were enlarged by.
     const float rix = (float)r.x, riy = (float)r.y, riz = (float)r.z;
+    const float nox = -(float)(o.x * r.x), noy = -(float)(o.y * r.y), noz = -(float)(o.z * r.z);
     const int oct = (d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0);
+    const int link_off = 32 + oct * 8;
     const double* sph = (const double*)(img + sv.off_sph);
     const double* tri = (const double*)(img + sv.off_tri);
     const double* cyl = (const double*)(img + sv.off_cyl);
@@ -386,26 +390,27 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
     best.t = kAny ? t_limit : __builtin_inf();
     int best_key = -2147483647 - 1;
     float bound = kAny ? (float)(t_limit * 1.00003) : __builtin_inff();
-    const float kSlack = 2e-5f;  // fp32 rounding (1e-6) + hit points displaced along the ray (1e-5 t)
-    int i = 0;
+    // enter (1 - s) <= exit (1 + s) with s = 2e-5 [fp32 rounding (1e-6) + hit points displaced along the
+    // ray (1e-5 t)], written as max(enter, 0) * (1 - 2.1 s) <= exit: the same for enter > 0, and for
+    // enter <= 0 both reduce to exit >= 0.
+    const float kShrink = 1.0f - 4.2e-5f;
+    int cur = sv.off_fnodes;  // byte offset of the node record in the image; < 0: done
     for (;;) {
         int lf = 0, lc = 0;
-        while (i >= 0) {
-            const float4* fb = (const float4*)(img + sv.off_fnodes + i * 32);
-            float4 b0 = fb[0], b1 = fb[1];  // lo.x lo.y lo.z hi.x | hi.y hi.z first count
-            int2 lk = *(const int2*)(img + sv.off_flinks + (i * 8 + oct) * 8);
+        while (cur >= 0) {
+            const unsigned char* np = img + cur;
+            float4 b0 = *(const float4*)np, b1 = *(const float4*)(np + 16);  // lo.x lo.y lo.z hi.x | hi.y hi.z first count
+            int2 lk = *(const int2*)(np + link_off);
             ++tally.box;
-            float x0 = (b0.x - ofx) * rix, x1 = (b0.w - ofx) * rix;
-            float y0 = (b0.y - ofy) * riy, y1 = (b1.x - ofy) * riy;
-            float z0 = (b0.z - ofz) * riz, z1 = (b1.y - ofz) * riz;
+            float x0 = __builtin_fmaf(b0.x, rix, nox), x1 = __builtin_fmaf(b0.w, rix, nox);
+            float y0 = __builtin_fmaf(b0.y, riy, noy), y1 = __builtin_fmaf(b1.x, riy, noy);
+            float z0 = __builtin_fmaf(b0.z, riz, noz), z1 = __builtin_fmaf(b1.y, riz, noz);
             float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
             float exit = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            float enter_lo = enter - kSlack * fabsf(enter);
-            float exit_hi = exit + kSlack * fabsf(exit);
-            bool pass = (enter_lo <= exit_hi) && (exit_hi >= 0.f) && (enter_lo <= bound);
+            bool fail = fmaxf(enter, 0.f) * kShrink > fminf(exit, bound);  // a NaN passes
             int cnt = __float_as_int(b1.w);
-            i = pass ? lk.x : lk.y;
-            if (pass && cnt > 0) {
+            cur = fail ? lk.y : lk.x;
+            if (!fail && cnt > 0) {
                 lf = __float_as_int(b1.z);
                 lc = cnt;
                 break;
@@ -441,7 +446,7 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
                 if (t < t_limit) {
                     best.t = t;
                     best.ref = ref;
-                    i = -1;  // occluded: leave the walk
+                    cur = -1;  // occluded: leave the walk
                     break;
                 }
             } else if (t < best.t || (t == best.t && lp.z > best_key)) {
@@ -1347,6 +1352,7 @@ __global__ void resolve_kernel(double* buf, long long n_pixels, int pixel_sample
 
 #include "wavefront_kernels.inc"
 #include "blockwave_kernels.inc"
+#include "fused_kernels.inc"
 
 // ---- diagnostics kernels (rt_debug_*) ------------------------------------------------------------
 __global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const double* origins, const double* dirs,
@@ -1441,6 +1447,7 @@ struct rt_context {
     int traversal = 3;           // 0 ref, 1 walk (same visits as the reference), 2 cull (+ any-hit shadows), 3 filter BVH
     bool wavefront = true;       // RT_PIPELINE=mega selects the persistent per-pixel kernel
     bool level_kernels = false;  // RT_PIPELINE=levels: one kernel per phase and depth instead of one per frame
+    int fused = -1;              // one pass per level (fused_kernels.inc): -1 = Whitted yes, path trace no; RT_PIPELINE=fused / block force it
     unsigned* d_bw_info = nullptr;
     int bw_info_blocks = 0;
     unsigned long long generation = 1;  // bumped by upload / set_camera / set_params
@@ -1635,6 +1642,7 @@ int rt_create(rt_context** out, int device) {
     const char* pipe = std::getenv("RT_PIPELINE");
     c->wavefront = !(pipe && std::strcmp(pipe, "mega") == 0) && c->fast_traversal;
     c->level_kernels = pipe && std::strcmp(pipe, "levels") == 0;
+    c->fused = pipe && std::strcmp(pipe, "fused") == 0 ? 1 : (pipe && std::strcmp(pipe, "block") == 0 ? 0 : -1);
     c->n_cus = prop.multiProcessorCount;
     std::memset(&c->sv, 0, sizeof c->sv);
     hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
@@ -1744,12 +1752,13 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sv.off_ref = off;     off = align16(off + s->n_prims * 4);
     rt::FilterBVH fb;
     rt::build_filter_bvh(s, s->use_bvh ? &bvh : nullptr, fb);
+    // scale cap: b * (1/d) with |1/d| <= 2^60 must stay finite in fp32 (closest_hit_fbvh)
+    if (!(fb.scene_scale <= 0x1p40)) fb.ok = false;
     sv.fbvh_ok = fb.ok ? 1 : 0;
     sv.n_fnodes = fb.n_nodes;
     sv.scene_scale = fb.scene_scale;
     if (fb.ok) {
-        sv.off_fnodes = off;   off = align16(off + fb.n_nodes * 32);
-        sv.off_flinks = off;   off = align16(off + fb.n_nodes * 64);
+        sv.off_fnodes = off;   off = align16(off + fb.n_nodes * kFNodeBytes);
         sv.off_leafprim = off; off = align16(off + s->n_prims * 16);
     }
     sv.image_bytes = std::max(off, 16);
@@ -1796,12 +1805,17 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (s->n_prims) std::memcpy(image.data() + sv.off_ref, ref_of_gid.data(), (size_t)s->n_prims * 4);
     if (fb.ok) {
         for (int i = 0; i < fb.n_nodes; ++i) {
-            unsigned char* n = image.data() + sv.off_fnodes + (size_t)i * 32;
+            unsigned char* n = image.data() + sv.off_fnodes + (size_t)i * kFNodeBytes;
             std::memcpy(n, &fb.box[(size_t)i * 6], 24);
             std::memcpy(n + 24, &fb.leaf_first[i], 4);
             std::memcpy(n + 28, &fb.leaf_count[i], 4);
+            int links[16];  // node indices -> byte offsets in the image, so that a walk step is one add
+            for (int k = 0; k < 16; ++k) {
+                int to = fb.links[(size_t)i * 16 + k];
+                links[k] = to < 0 ? -1 : sv.off_fnodes + to * kFNodeBytes;
+            }
+            std::memcpy(n + 32, links, 64);
         }
-        std::memcpy(image.data() + sv.off_flinks, fb.links.data(), fb.links.size() * 4);
         for (int k = 0; k < s->n_prims; ++k) {
             int rec[4] = {ref_of_gid[fb.leaf_prim[(size_t)k * 4]], fb.leaf_prim[(size_t)k * 4 + 1], fb.leaf_prim[(size_t)k * 4 + 2], 0};
             std::memcpy(image.data() + sv.off_leafprim + (size_t)k * 16, rec, 16);

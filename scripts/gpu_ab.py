@@ -18,7 +18,7 @@ cases = [("clutter_500", 3840, 2160, 1), ("clutter_500", 1200, 800, 1), ("clutte
          ("binary_primitives", 3840, 2160, 1), ("pathtrace", 480, 270, 1), ("final", 480, 270, 1)]
 ctx = {}
 for mode in ["ref", "fast"]:
-    os.environ["RT_PIPELINE"] = "levels" if mode == "ref" else "block"
+    os.environ["RT_PIPELINE"] = os.environ.get("AB_REF", "block") if mode == "ref" else os.environ.get("AB_FAST", "fused")
     ctx[mode] = rt.Renderer(0)
 for name, w, h, bvh in cases:
     sf = rt.SceneFile(f"scenes/{name}.json", width=w, height=h)
