@@ -1353,6 +1353,7 @@ __global__ void resolve_kernel(double* buf, long long n_pixels, int pixel_sample
 #include "wavefront_kernels.inc"
 #include "blockwave_kernels.inc"
 #include "fused_kernels.inc"
+#include "gridwave_kernels.inc"
 
 // ---- diagnostics kernels (rt_debug_*) ------------------------------------------------------------
 __global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const double* origins, const double* dirs,
@@ -1449,6 +1450,11 @@ struct rt_context {
     bool level_kernels = false;  // RT_PIPELINE=levels: one kernel per phase and depth instead of one per frame
     int fused = -1;              // one pass per level (fused_kernels.inc): -1 = Whitted yes, path trace no; RT_PIPELINE=fused / block force it
     unsigned* d_bw_info = nullptr;
+    uint2* d_gw_lvl = nullptr;       // gridwave: per level, per workgroup (first id, count)
+    unsigned* d_gw_barrier = nullptr;
+    long long* d_gw_timing = nullptr;
+    int gw_lvl_blocks = 0;
+    bool gridwave = true;            // RT_PIPELINE=fused / block select the per-workgroup pipelines instead
     int bw_info_blocks = 0;
     unsigned long long generation = 1;  // bumped by upload / set_camera / set_params
     int n_point_lights = 0, n_area_lights = 0;
@@ -1515,6 +1521,7 @@ int upload(T** dst, const std::vector<T>& src) {
 
 #include "wavefront_host.inc"
 #include "blockwave_host.inc"
+#include "gridwave_host.inc"
 
 int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_dev, bool accumulate_only) {
     if (!c->have_scene || !c->have_camera || !c->have_params)
@@ -1562,7 +1569,9 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     c->last_was_wavefront = c->wavefront;
     if (c->wavefront) {
         c->scene_in_lds = c->sv.image_bytes <= kMaxLdsImage ? 1 : 0;
-        return c->level_kernels ? launch_wavefront(c, stream, A, accumulate_only) : launch_blockwave(c, stream, A, accumulate_only);
+        if (c->level_kernels) return launch_wavefront(c, stream, A, accumulate_only);
+        if (c->gridwave && p.mode != RT_MODE_PATHTRACE && p.max_depth > 0) return launch_gridwave(c, stream, A);
+        return launch_blockwave(c, stream, A, accumulate_only);
     }
 
     // persistent grid: as many workgroups as the chip holds at once
@@ -1643,6 +1652,7 @@ int rt_create(rt_context** out, int device) {
     c->wavefront = !(pipe && std::strcmp(pipe, "mega") == 0) && c->fast_traversal;
     c->level_kernels = pipe && std::strcmp(pipe, "levels") == 0;
     c->fused = pipe && std::strcmp(pipe, "fused") == 0 ? 1 : (pipe && std::strcmp(pipe, "block") == 0 ? 0 : -1);
+    c->gridwave = c->fused < 0;
     c->n_cus = prop.multiProcessorCount;
     std::memset(&c->sv, 0, sizeof c->sv);
     hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
@@ -1668,6 +1678,9 @@ void rt_destroy(rt_context* c) {
     (void)hipFree(c->d_wf_shadow);
     (void)hipFree(c->d_wf_state);
     (void)hipFree(c->d_bw_info);
+    (void)hipFree(c->d_gw_lvl);
+    (void)hipFree(c->d_gw_barrier);
+    (void)hipFree(c->d_gw_timing);
     (void)hipFree(c->d_ticket);
     (void)hipFree(c->d_counters);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
