@@ -57,7 +57,11 @@ constexpr int kSphereDoubles = 4;
 constexpr int kTriDoubles = 12;
 constexpr int kCylDoubles = 8;
 constexpr int kBlock = 512;          // threads per workgroup (per-pixel kernel)
-constexpr int kTraceBlock = 1024;    // wavefront trace kernels: one LDS scene image per 16 waves
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 1024
+#endif
+constexpr int kTraceBlock = RT_TRACE_BLOCK;  // threads per workgroup of the frame kernels: one LDS scene image per 16 waves
+constexpr int kFusedBlock = 768;  // fused Whitted kernels: 168 VGPRs per lane (428 B of scratch instead of 604 B) beat a fourth wave per SIMD
 constexpr int kMaxLdsImage = 150 * 1024;
 constexpr int kNF = 26;              // doubles per frame
 constexpr int kMaxDepthLimit = 64;
@@ -365,6 +369,10 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
 // ray's octant through precomputed links (no stack), culled against the best t so far.  Leaves: the
 // reference's own two fp64 tests -- the gate box (BoundingBox::intersect on the BVHNode that holds
 // the primitive) and the primitive -- and the reference's tie rule via the DFS-order key.
+typedef float F2 __attribute__((ext_vector_type(2)));
+#ifndef RT_PK_SLAB
+#define RT_PK_SLAB 0  // v_pk_fma_f32 form measured 4 % slower (pairs of broadcast operands cost 6 more VGPRs)
+#endif
 template <bool kAny, typename P>
 RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tally, double t_limit = 0.0) {
     const double reach = 4.0 * sv.scene_scale;
@@ -399,14 +407,21 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
         int lf = 0, lc = 0;
         while (cur >= 0) {
             const unsigned char* np = img + cur;
-            float4 b0 = *(const float4*)np, b1 = *(const float4*)(np + 16);  // lo.x lo.y lo.z hi.x | hi.y hi.z first count
+            float4 b0 = *(const float4*)np, b1 = *(const float4*)(np + 16);  // lo.x hi.x lo.y hi.y | lo.z hi.z first count
             int2 lk = *(const int2*)(np + link_off);
             ++tally.box;
-            float x0 = __builtin_fmaf(b0.x, rix, nox), x1 = __builtin_fmaf(b0.w, rix, nox);
-            float y0 = __builtin_fmaf(b0.y, riy, noy), y1 = __builtin_fmaf(b1.x, riy, noy);
-            float z0 = __builtin_fmaf(b0.z, riz, noz), z1 = __builtin_fmaf(b1.y, riz, noz);
-            float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-            float exit = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            // both planes of an axis in one packed FMA (v_pk_fma_f32)
+#if RT_PK_SLAB
+            const F2 tx = __builtin_elementwise_fma(F2{b0.x, b0.y}, F2{rix, rix}, F2{nox, nox});
+            const F2 ty = __builtin_elementwise_fma(F2{b0.z, b0.w}, F2{riy, riy}, F2{noy, noy});
+            const F2 tz = __builtin_elementwise_fma(F2{b1.x, b1.y}, F2{riz, riz}, F2{noz, noz});
+#else
+            const F2 tx = F2{__builtin_fmaf(b0.x, rix, nox), __builtin_fmaf(b0.y, rix, nox)};
+            const F2 ty = F2{__builtin_fmaf(b0.z, riy, noy), __builtin_fmaf(b0.w, riy, noy)};
+            const F2 tz = F2{__builtin_fmaf(b1.x, riz, noz), __builtin_fmaf(b1.y, riz, noz)};
+#endif
+            float enter = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+            float exit = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
             bool fail = fmaxf(enter, 0.f) * kShrink > fminf(exit, bound);  // a NaN passes
             int cnt = __float_as_int(b1.w);
             cur = fail ? lk.y : lk.x;
@@ -1841,7 +1856,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (fb.ok) {
         for (int i = 0; i < fb.n_nodes; ++i) {
             unsigned char* n = image.data() + sv.off_fnodes + (size_t)i * kFNodeBytes;
-            std::memcpy(n, &fb.box[(size_t)i * 6], 24);
+            const float* bx = &fb.box[(size_t)i * 6];  // lo xyz, hi xyz -> (lo, hi) pairs per axis
+            const float pairs[6] = {bx[0], bx[3], bx[1], bx[4], bx[2], bx[5]};
+            std::memcpy(n, pairs, 24);
             std::memcpy(n + 24, &fb.leaf_first[i], 4);
             std::memcpy(n + 28, &fb.leaf_count[i], 4);
             int links[16];  // node indices -> byte offsets in the image, so that a walk step is one add
