@@ -15,8 +15,10 @@ A "step" is one pass of the hot path over one frame of the workload:
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) ONE frame is split over the
 ranks -- row bands for Whitted, strata ranges for path tracing -- and recombined on rank 0's
-device through RCCL (gather of disjoint bands / reduce of partial sums), inside the timed region.
-Total work is fixed, so "scaling" is "strong".
+device through RCCL inside the timed region: a gather of the bands as PPM bytes (the reference's
+int(255.999 * c), done on the device: an eighth of the fp64 data) / a reduce of the fp64 partial
+sums.  Frames are pipelined two deep, so the collective of frame k overlaps the kernels of frame
+k+1.  Total work is fixed, so "scaling" is "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` prices the persistent render kernel against the fp64
 VALU peak WITHOUT FMA credit (contraction is off for parity): algorithmic ops = 24 per box test
@@ -104,20 +106,41 @@ def main():
     rw.close()
     stream = torch.cuda.current_stream().cuda_stream
 
+    # Frames are pipelined two deep: the collective of frame k (RCCL stream) overlaps the kernels of frame
+    # k+1 (this stream).  Whitted frames travel as PPM bytes (rt_quantize_device), path-trace passes as
+    # fp64 partial sums (the division / tone map / gamma come after the reduction).
     if pathtrace:
-        accum = torch.empty(H * W * 3, dtype=torch.float64, device=dev)
+        pipe = rtd.AccumulatorPipeline(world, H * W * 3, dev)
     else:
-        gatherer = rtd.BandGatherer(rank, world, H, W, dev, band_rows=P.band_rows)
+        pipe = rtd.FramePipeline(rank, world, H, W, dev, band_rows=P.band_rows)
+        n_mine = rows * W * 3
 
-    def step():
+    def enqueue(k, ev=None):
         if pathtrace:
+            accum = pipe.target(k)
+            if ev: ev[0].record()
             r.accumulate_device(accum.data_ptr(), stream=stream)
-            rtd.reduce_accumulators(accum, world)
-            if rank == 0:
-                r.resolve_device(accum.data_ptr(), H * W, stream=stream)
+            if ev: ev[1].record()
         else:
-            r.render_device(gatherer.mine.data_ptr(), None, stream=stream)
-            gatherer.gather()
+            rgb, u8 = pipe.target(k)
+            if ev: ev[0].record()
+            r.render_device(rgb.data_ptr(), None, stream=stream)
+            if ev: ev[1].record()
+            r.quantize_device(rgb.data_ptr(), n_mine, u8.data_ptr(), stream=stream)
+        pipe.submit(k)
+
+    def finish(k):
+        out = pipe.complete(k)
+        if pathtrace and rank == 0:
+            r.resolve_device(out.data_ptr(), H * W, stream=stream)
+
+    def run(n, events=None):
+        for k in range(n):
+            enqueue(k, events[k] if events else None)
+            if k > 0:
+                finish(k - 1)
+        if n > 0:
+            finish(n - 1)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -125,21 +148,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     sync_all()
-    kernel_ms = []
-    rays_local = 0
+    # per-launch duration of the render kernels: HIP events on the stream they are launched on
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # per-launch HIP-event time of the render kernel on its own stream (rt_get_stats waits on the
-        # event recorded right after the kernel; the following collective is already enqueued)
-        st = r.stats()
-        kernel_ms.append(st.kernel_ms)
-        rays_local = st.rays
+    run(args.steps, events)
     sync_all()
     elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
     st = r.stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -175,7 +192,9 @@ def main():
                        "parallelism": ("strata-range x%d + RCCL reduce" if pathtrace else "row-band x%d + RCCL gather") % world},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VALU_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
-                         "kernel": "wavefront frame (raygen + per depth: trace, shadow, shade; combine; resolve)", "kernel_ms": k_ms,
+                         "kernel": ("bw_kernel + bw_accumulate_path_kernel per batch of strata (per depth: trace, shadow, shade; combine)" if pathtrace
+                                    else "fw_roots_kernel (level 0) + fw_kernel (depth >= 1: fused trace/shadow/shade per level, combine, tone map)"),
+                         "kernel_ms": k_ms,
                          "ops_per_ray": alg_ops / max(rays, 1.0),
                          "reference_box_tests_per_ray": boxes / max(rays, 1.0),
                          "executed_box_tests_per_ray": float(done[0].item()) / max(rays, 1.0),

@@ -226,6 +226,12 @@ int rt_render_device(rt_context* ctx, void* stream, double* rgb_dev, int32_t* hi
  * division, tone map, exposure or gamma: those are non-linear and come after the reduction. */
 int rt_pathtrace_accumulate_device(rt_context* ctx, void* stream, double* accum_dev);
 
+/* The component conversion of RayTracer::writeImageToPPM (RayTracer.cpp:359-362), int(255.999 * c),
+ * on n_values doubles of a device buffer -> bytes in another device buffer: the PPM's payload, an
+ * eighth of the fp64 frame, which is what a multi-GPU job moves over xGMI to the rank that writes
+ * the file. */
+int rt_quantize_device(rt_context* ctx, void* stream, const double* rgb_dev, int64_t n_values, uint8_t* out_dev);
+
 /* RayTracer.cpp:301-315 (path trace) on n_pixels pixels of a device buffer in place:
  * / pixelSamples, tone map, * exposure, pow(1/2.2), clamp. */
 int rt_pathtrace_resolve_device(rt_context* ctx, void* stream, double* accum_dev,

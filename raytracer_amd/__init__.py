@@ -109,6 +109,10 @@ class Renderer:
         capi.check(self._lib.rt_pathtrace_resolve_device(self._h, stream, accum_ptr, n_pixels),
                    "rt_pathtrace_resolve_device")
 
+    def quantize_device(self, rgb_ptr, n_values, out_ptr, stream=None):
+        """int(255.999 * c) per component (the PPM payload) from one device buffer into another."""
+        capi.check(self._lib.rt_quantize_device(self._h, stream, rgb_ptr, n_values, out_ptr), "rt_quantize_device")
+
     def stats(self):
         st = capi.Stats()
         capi.check(self._lib.rt_get_stats(self._h, C.byref(st)), "rt_get_stats")

@@ -1382,6 +1382,15 @@ __global__ void resolve_kernel(double* buf, long long n_pixels, int pixel_sample
     buf[k * 3 + 2] = clamp01(color.z);
 }
 
+// writeImageToPPM's component conversion (RayTracer.cpp:359-362): int(255.999 * c), c already in [0, 1]
+__global__ void __launch_bounds__(256) quantize_kernel(const double* rgb, long long n, unsigned char* out) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int v = (int)(255.999 * rgb[i]);
+        out[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
 #include "wavefront_kernels.inc"
 #include "blockwave_kernels.inc"
 #include "fused_kernels.inc"
@@ -1999,6 +2008,16 @@ int rt_pathtrace_resolve_device(rt_context* c, void* stream, double* accum_dev, 
     long long grid = (n_pixels + block - 1) / block;
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, accum_dev, (long long)n_pixels,
                        c->params.pixel_samples, c->params.tonemap, c->params.exposure);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_quantize_device(rt_context* c, void* stream, const double* rgb_dev, int64_t n_values, uint8_t* out_dev) {
+    if (!c || !rgb_dev || !out_dev || n_values < 0) return rt::set_error(RT_ERR_INVALID, "rt_quantize_device: bad argument");
+    if (n_values == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    long long grid = std::min<long long>((n_values + 255) / 256, (long long)c->n_cus * 16);
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, rgb_dev, (long long)n_values, out_dev);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

@@ -57,6 +57,81 @@ class BandGatherer:
         return self.frame
 
 
+class FramePipeline:
+    """Whitted frames of a multi-GPU job, pipelined: every rank renders its bands of frame k into one of
+    `depth` device buffers, converts them to PPM bytes (rt_quantize_device: an eighth of the fp64 data), and
+    the gather of those bytes to rank 0 runs asynchronously (RCCL's own stream, xGMI) while frame k+1 is
+    being rendered.  complete(k) makes the current stream wait for frame k's gather and scatters its rows
+    into `frame` (rank 0: uint8 [H, W, 3], row 0 = bottom row)."""
+
+    def __init__(self, rank, world, height, width, device, band_rows=8, depth=2):
+        self.rank, self.world, self.H, self.W, self.depth = rank, world, height, width, depth
+        self.slot_rows = max_band_rows(world, height, band_rows)
+        n = self.slot_rows * width * 3
+        self.rgb = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(depth)]
+        self.u8 = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.frame = None
+        self.slots = None
+        self.index = None
+        if rank == 0 and world > 1:
+            self.frame = torch.empty(height, width, 3, dtype=torch.uint8, device=device)
+            self.slots = [[torch.empty_like(self.u8[0]) for _ in range(world)] for _ in range(depth)]
+            self.index = [torch.tensor(band_rows_of(q, world, height, band_rows), dtype=torch.long, device=device)
+                          for q in range(world)]
+
+    def target(self, k):
+        """(fp64 render target, uint8 quantization target) of frame k."""
+        return self.rgb[k % self.depth], self.u8[k % self.depth]
+
+    def submit(self, k):
+        """Call after frame k's render and quantization were enqueued on the current stream."""
+        i = k % self.depth
+        if self.world > 1:
+            self.pending[i] = dist.gather(self.u8[i], self.slots[i] if self.rank == 0 else None, dst=0, async_op=True)
+
+    def complete(self, k):
+        """Frame k is assembled on rank 0 once the current stream reaches this point."""
+        i = k % self.depth
+        if self.world == 1:  # one rank's compact buffer IS the frame (bands in order)
+            self.frame = self.u8[i][: self.H * self.W * 3].view(self.H, self.W, 3)
+            return self.frame
+        work, self.pending[i] = self.pending[i], None
+        if work is not None:
+            work.wait()
+        if self.rank != 0:
+            return None
+        for q in range(self.world):
+            n = self.index[q].numel()
+            self.frame.index_copy_(0, self.index[q], self.slots[i][q][: n * self.W * 3].view(n, self.W, 3))
+        return self.frame
+
+
+class AccumulatorPipeline:
+    """Path-trace passes of a multi-GPU job, pipelined the same way: pass k's partial radiance sums are
+    reduced (SUM) to rank 0 asynchronously while pass k+1 runs."""
+
+    def __init__(self, world, n_values, device, depth=2):
+        self.world, self.depth = world, depth
+        self.accum = [torch.empty(n_values, dtype=torch.float64, device=device) for _ in range(depth)]
+        self.pending = [None] * depth
+
+    def target(self, k):
+        return self.accum[k % self.depth]
+
+    def submit(self, k):
+        i = k % self.depth
+        if self.world > 1:
+            self.pending[i] = dist.reduce(self.accum[i], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+
+    def complete(self, k):
+        i = k % self.depth
+        work, self.pending[i] = self.pending[i], None
+        if work is not None:
+            work.wait()
+        return self.accum[i]
+
+
 def reduce_accumulators(accum, world):
     """Sum of the per-rank radiance accumulators on rank 0 (in place)."""
     if world > 1:

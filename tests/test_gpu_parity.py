@@ -268,3 +268,21 @@ def test_bad_arguments_are_rejected(renderer):
     with pytest.raises(rt.RtError):
         renderer.upload(s.desc)
     renderer.load(sf)  # leave the shared context usable
+
+
+def test_quantize_device_is_the_ppm_conversion(renderer):
+    """rt_quantize_device == int(255.999 * c) (RayTracer.cpp:359-362) on a rendered frame, device to device."""
+    import torch
+    sf = scene_util.load("mirror_glass_cylinder", 300, 200)
+    renderer.load(sf)
+    n = 300 * 200 * 3
+    rgb = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    u8 = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    renderer.render_device(rgb.data_ptr(), None, stream=s)
+    renderer.quantize_device(rgb.data_ptr(), n, u8.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    host = rgb.cpu().numpy()
+    assert np.array_equal(u8.cpu().numpy(), (255.999 * host).astype(np.int32).astype(np.uint8))
+    orgb, _, _, _ = oracle_lib.render(sf.desc, sf.camera, sf.params, want_hit=False)
+    assert np.abs(host.reshape(200, 300, 3) - orgb).max() <= TIGHT_ABS

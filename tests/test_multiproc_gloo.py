@@ -36,6 +36,33 @@ def _worker(rank, world, port, q):
         frame = g.gather()
         if rank == 0:
             out["bands_equal"] = bool(np.array_equal(frame.numpy(), full))
+        # ---- the pipelined form bench.py uses: PPM bytes, two frames in flight ----------------------
+        u8_full = (255.999 * full).astype(np.int32).astype(np.uint8)   # rt_quantize_device's conversion
+        fp = rtd.FramePipeline(rank, world, P.height, P.width, torch.device("cpu"))
+        ok = True
+        for k in range(3):  # frame k = the frame with every byte shifted by k (so that a stale buffer shows)
+            rgb_t, u8_t = fp.target(k)
+            mine8 = torch.from_numpy(np.ascontiguousarray(u8_full[rows] + k))
+            u8_t[: mine8.numel()] = mine8.reshape(-1)
+            fp.submit(k)
+            if k > 0:
+                fr = fp.complete(k - 1)
+                if rank == 0:
+                    ok = ok and bool(np.array_equal(fr.numpy(), u8_full + (k - 1)))
+        fr = fp.complete(2)
+        if rank == 0:
+            out["pipeline_equal"] = ok and bool(np.array_equal(fr.numpy(), u8_full + 2))
+        ap = rtd.AccumulatorPipeline(world, 8, torch.device("cpu"))
+        for k in range(3):
+            ap.target(k).fill_(float(rank + 1 + k))
+            ap.submit(k)
+            if k > 0:
+                got = ap.complete(k - 1)
+                if rank == 0:
+                    ok = ok and bool((got == float(sum(r + 1 + (k - 1) for r in range(world)))).all())
+        got = ap.complete(2)
+        if rank == 0:
+            out["accum_pipeline"] = ok and bool((got == float(sum(r + 1 + 2 for r in range(world)))).all())
         # ---- path trace: strata ranges -> reduce -> resolve --------------------------------------
         pt = scene_util.load("pathtrace", 24, 16)
         Q = pt.params
@@ -74,6 +101,7 @@ def test_two_ranks_reassemble_the_frame():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out["bands_equal"] and out["accum_close"] and out["resolved_close"]
+    assert out["pipeline_equal"] and out["accum_pipeline"]
     assert out["ranges"] == [(2, 2), (0, 1), (2, 2), (1, 2)]
 
 
