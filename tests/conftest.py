@@ -74,6 +74,30 @@ def renderer_literal():
 
 
 @pytest.fixture(scope="session")
+def renderer_grid():
+    """Per-level dealing over the whole grid: cooperative launch with grid barriers (gridwave_kernels.inc)."""
+    r = _make({"RT_PIPELINE": "grid"})
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
+def renderer_block():
+    """Three-phase (trace | shadow | shade) per-workgroup pipeline for Whitted frames too."""
+    r = _make({"RT_PIPELINE": "block"})
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
+def renderer_fused_whole():
+    """Fused pipeline with level 0 inside the frame kernel (no fw_roots_kernel), also for path tracing."""
+    r = _make({"RT_PIPELINE": "fused", "RT_SPLIT_ROOTS": "0"})
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
 def renderer():
     """One rt_context on cuda:0 for the whole GPU session.  No fallback: fails if the HIP library
     or the device is missing."""

@@ -87,6 +87,17 @@ def test_other_gpu_implementations_agree_and_count_like_the_reference(request, w
         assert_frame_parity(*run_both(r, sf, desc=desc, params=P), check_counts=True)
 
 
+@pytest.mark.parametrize("name", ["clutter_500", "mirror_glass_cylinder", "binary_primitives", "textured"])
+@pytest.mark.parametrize("which", ["grid", "block", "fused_whole"])
+def test_selectable_pipelines_agree(request, which, name):
+    """RT_PIPELINE=grid / block / fused with RT_SPLIT_ROOTS=0: the same frame, hit IDs and ray count as the
+    oracle (and therefore as the default fw_roots_kernel + fw_kernel path), including the first-frame
+    arena overflow and retry that 300x200 clutter_500 provokes."""
+    r = request.getfixturevalue("renderer_" + which)
+    sf = scene_util.load(name, 300, 200)
+    assert_frame_parity(*run_both(r, sf))
+
+
 @pytest.mark.parametrize("bvh", [0, 1])
 def test_clutter_500_both_tie_rules(renderer, bvh, golden_hits):
     sf = scene_util.load("clutter_500", 300, 200)

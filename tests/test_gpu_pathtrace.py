@@ -50,7 +50,7 @@ def test_same_rng_same_image(renderer, name, spp, ls):
     assert_pt_parity(*gpu_and_oracle(renderer, sf, P))
 
 
-@pytest.mark.parametrize("which", ["levels", "mega"])
+@pytest.mark.parametrize("which", ["levels", "mega", "fused_whole"])
 def test_other_pipelines_path_trace_the_same_image(request, which):
     r = request.getfixturevalue("renderer_" + which)
     sf = scene_util.load("final", 120, 80)
