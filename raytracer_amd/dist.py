@@ -75,10 +75,17 @@ class FramePipeline:
         self.slots = None
         self.index = None
         if rank == 0 and world > 1:
-            self.frame = torch.empty(height, width, 3, dtype=torch.uint8, device=device)
-            self.slots = [[torch.empty_like(self.u8[0]) for _ in range(world)] for _ in range(depth)]
-            self.index = [torch.tensor(band_rows_of(q, world, height, band_rows), dtype=torch.long, device=device)
-                          for q in range(world)]
+            # one receive buffer per frame in flight, [world, slot_rows, W*3]; row H of `_frame` is a dump for
+            # the padding rows of ranks whose share is short, so that ONE index_copy_ assembles a frame
+            self._frame = torch.empty(height + 1, width * 3, dtype=torch.uint8, device=device)
+            self.frame = self._frame[:height].view(height, width, 3)
+            self._recv = [torch.empty(world, self.slot_rows, width * 3, dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.slots = [[self._recv[i][q].view(-1) for q in range(world)] for i in range(depth)]
+            idx = torch.full((world, self.slot_rows), height, dtype=torch.long)
+            for q in range(world):
+                rows = band_rows_of(q, world, height, band_rows)
+                idx[q, : len(rows)] = torch.tensor(rows, dtype=torch.long)
+            self.index = idx.view(-1).to(device)
 
     def target(self, k):
         """(fp64 render target, uint8 quantization target) of frame k."""
@@ -101,9 +108,7 @@ class FramePipeline:
             work.wait()
         if self.rank != 0:
             return None
-        for q in range(self.world):
-            n = self.index[q].numel()
-            self.frame.index_copy_(0, self.index[q], self.slots[i][q][: n * self.W * 3].view(n, self.W, 3))
+        self._frame.index_copy_(0, self.index, self._recv[i].view(self.world * self.slot_rows, self.W * 3))
         return self.frame
 
 
