@@ -201,6 +201,13 @@ def main():
                          "executed_prim_tests_per_ray": float(done[1].item()) / max(rays, 1.0),
                          "note": "fp64 ops without FMA credit (contraction off for parity); peak = 78.6/2"},
         }
+        # HBM bytes per frame from the PMC passes (collected offline with rocprofv3 --pmc, see the file): not
+        # measurable inside this process, so it is quoted from the committed profile of the same workload
+        tpath = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
+        if not pathtrace and world == 1 and os.path.exists(tpath):
+            tr = json.load(open(tpath))
+            line["roofline"]["traffic"] = tr["fetch_bytes_raw"] + tr["write_bytes"]
+            line["roofline"]["traffic_source"] = tr["source"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sf, desc, base, pathtrace)
         print(json.dumps(line), flush=True)
