@@ -52,6 +52,7 @@ using namespace rtd;
 namespace {
 
 constexpr int kNodeBytes = 64;  // 6 doubles box, int skip, int ref0, int ref1, int pad
+constexpr int kLeafBytes = 64;   // filter BVH leaf record: primitive ref, gate flag, tie key, pad, gate box 6 doubles
 constexpr int kFNodeBytes = 96;  // filter BVH: 6 floats box, leaf first, leaf count, 8 x (pass, fail) links as image offsets
 constexpr int kSphereDoubles = 4;
 constexpr int kTriDoubles = 12;
@@ -100,11 +101,13 @@ struct SceneView {
     int off_nodes, off_sph, off_tri, off_cyl;         // byte offsets into the image
     int off_gid_sph, off_gid_tri, off_gid_cyl;        // int tables: typed index -> primitive ID
     int off_ref;                                      // int table: primitive ID -> ref (linear scan)
+    int off_matidx, off_mat, mat_staged;              // int table: primitive ID -> material; DMaterial records; records inside lds_bytes
     int image_bytes;
+    int lds_bytes;  // prefix of the image the frame kernels stage into LDS (everything the chosen traversal touches per ray)
     int n_lights;
     int regular;  // every coordinate is 0 or within [2^-300, 2^300]: shared-reciprocal division is exact
     int fbvh_ok, n_fnodes;                       // filter BVH present (fbvh_build.cpp)
-    int off_fnodes, off_leafprim;                // 96 B nodes (box, leaf range, [octant] int2 links), int4 leaf records
+    int off_fnodes, off_leafprim;                // 96 B nodes (box, leaf range, [octant] int2 links), 64 B leaf records
     double scene_scale;
     const unsigned char* image;  // global copy of the image
     const DMaterial* materials;
@@ -378,7 +381,7 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
     const double reach = 4.0 * sv.scene_scale;
     bool eligible = sv.fbvh_ok && sv.regular && ray_regular(o, d) && fabs(d.x) >= 0x1p-60 && fabs(d.y) >= 0x1p-60 &&
                     fabs(d.z) >= 0x1p-60 && fabs(o.x) <= reach && fabs(o.y) <= reach && fabs(o.z) <= reach;
-    if (!eligible) return closest_hit_fast<false, kAny>(img, sv, o, d, tally, t_limit);
+    if (!eligible) return closest_hit_fast<false, kAny>(sv.image, sv, o, d, tally, t_limit);  // reference nodes: global copy only
     const double a = dot(d, d);
     const double two_a = 2.0 * a;
     const double r2a = refine_rcp(two_a);
@@ -434,9 +437,10 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
         if (lc == 0) break;
 #pragma unroll 1
         for (int k = 0; k < lc; ++k) {
-            int4 lp = *(const int4*)(img + sv.off_leafprim + (lf + k) * 16);  // ref, gate, key
+            const unsigned char* rec = img + sv.off_leafprim + (lf + k) * kLeafBytes;
+            int4 lp = *(const int4*)rec;  // ref, has gate, key; then the gate box (6 doubles)
             if (lp.y >= 0) {
-                const double* nb = (const double*)(img + sv.off_nodes + lp.y * kNodeBytes);
+                const double* nb = (const double*)(rec + 16);
                 double t_enter;
                 ++tally.box;
                 if (!box_hit_regular(nb, o, d, r, t_enter)) continue;
@@ -498,6 +502,16 @@ RT_DEV int gid_of_ref(P img, const SceneView& sv, int ref) {
     int type = ref_type(ref), idx = ref_index(ref);
     int off = type == RT_SPHERE ? sv.off_gid_sph : (type == RT_TRIANGLE ? sv.off_gid_tri : sv.off_gid_cyl);
     return ((const int*)(img + off))[idx];
+}
+
+// Material of a primitive: two reads of the scene image (LDS when it is staged) instead of a dependent
+// chain of global loads per shaded hit.
+template <typename P>
+RT_DEV const DMaterial& material_of(P img, const SceneView& sv, int ref) {
+    const int mi = ((const int*)(img + sv.off_matidx))[gid_of_ref(img, sv, ref)];
+    // the records themselves are in the staged part only when they fit next to the geometry
+    const unsigned char* base = sv.mat_staged ? (const unsigned char*)img : sv.image;
+    return *(const DMaterial*)(base + sv.off_mat + mi * (int)sizeof(DMaterial));
 }
 
 // point and normal of the winning primitive, computed from t exactly as the intersect functions
@@ -768,7 +782,7 @@ RT_DEV void advance_whitted(P img, const SceneView& sv, const RenderArgs& A, con
             if (h.t < ldist) in_shadow = true;
         }
         if (!in_shadow) {
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             D3 view = -normalize(dir);
             D3 ldir = normalize(lpos - point);
             D3 half = normalize(ldir + view);
@@ -792,7 +806,7 @@ RT_DEV void advance_whitted(P img, const SceneView& sv, const RenderArgs& A, con
             ref = h.ref;
             dir = L.d;
             hit_geometry(img, sv, h, L.o, L.d, point, normal);
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             tex = surface_colour(img, sv, m, ref, point);
             diffuse = mk(0, 0, 0);
             specular = mk(0, 0, 0);
@@ -821,7 +835,7 @@ RT_DEV void advance_whitted(P img, const SceneView& sv, const RenderArgs& A, con
             local = tex * 0.25 + diffuse + specular;  // ambient + diffuse + specular (:705, :746)
             pc = PC_AFTER_LIGHTS;
         } else if (pc == PC_AFTER_LIGHTS) {
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             pc = PC_AFTER_REFLECT;
             if (m.reflective) {  // :749-760
                 D3 n = normal;
@@ -842,7 +856,7 @@ RT_DEV void advance_whitted(P img, const SceneView& sv, const RenderArgs& A, con
                 }
             }
         } else if (pc == PC_AFTER_REFLECT) {
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             V = local;
             pc = PC_RETURN;
             if (m.refractive && depth < A.max_depth) {  // :764-800
@@ -886,7 +900,7 @@ RT_DEV void advance_whitted(P img, const SceneView& sv, const RenderArgs& A, con
             point = F.get3(depth, F_POINT);
             normal = F.get3(depth, F_NORMAL);
             dir = F.get3(depth, F_DIR);
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             if (stage == ST_REFLECT) {
                 local = F.get3(depth, F_A);
                 local = local * (1 - m.reflectivity) + V * m.reflectivity;
@@ -1055,7 +1069,7 @@ RT_DEV void advance_path(P img, const SceneView& sv, const RenderArgs& A, const 
         F.geti(depth, F_I1, packed, si);
         li = packed >> 8;
         const DLight& Lt = sv.lights[li];
-        const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+        const DMaterial& m = material_of(img, sv, ref);
         D3 view = -normalize(dir);
         if (Lt.type == RT_LIGHT_POINT) {  // RayTracer.cpp:602-637
             D3 lpos = ld3(Lt.position);
@@ -1107,7 +1121,7 @@ RT_DEV void advance_path(P img, const SceneView& sv, const RenderArgs& A, const 
             ref = h.ref;
             dir = L.d;
             hit_geometry(img, sv, h, L.o, L.d, point, normal);
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             albedo = surface_colour(img, sv, m, ref, point);
             pc = PC_LIGHT_LOOP;
             if (depth > 3) {  // Russian roulette (:530-536)
@@ -1157,7 +1171,7 @@ RT_DEV void advance_path(P img, const SceneView& sv, const RenderArgs& A, const 
             }
             pc = PC_MATERIAL;
         } else if (pc == PC_MATERIAL) {
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             D3 nf = normal;
             if (dot(dir, nf) > 0) nf = -nf;
             bool child_possible = depth + 1 < A.max_depth;  // else traceRayPath returns 0 with no ray
@@ -1240,7 +1254,7 @@ RT_DEV void advance_path(P img, const SceneView& sv, const RenderArgs& A, const 
             node = (unsigned)inode;
             stage &= 0xFF;
             direct = F.get3(depth, F_B);
-            const DMaterial& m = sv.materials[sv.mat_of_gid[gid_of_ref(img, sv, ref)]];
+            const DMaterial& m = material_of(img, sv, ref);
             if (stage == PT_MIRROR) {
                 V = direct + V * m.reflectivity;
             } else if (stage == PT_DIFFUSE) {
@@ -1293,7 +1307,7 @@ __global__ void __launch_bounds__(kBlock, RT_WAVES_PER_EU) render_kernel(SceneVi
         // stage the scene image in LDS, 16 bytes per lane per step
         const uint4* src = (const uint4*)sv.image;
         uint4* dst = (uint4*)lds_image;
-        int n16 = sv.image_bytes >> 4;
+        int n16 = sv.lds_bytes >> 4;
         for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
         __syncthreads();
         img = lds_image;
@@ -1612,15 +1626,15 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
 
     c->last_was_wavefront = c->wavefront;
     if (c->wavefront) {
-        c->scene_in_lds = c->sv.image_bytes <= kMaxLdsImage ? 1 : 0;
+        c->scene_in_lds = c->sv.lds_bytes <= kMaxLdsImage ? 1 : 0;
         if (c->level_kernels) return launch_wavefront(c, stream, A, accumulate_only);
         if (c->gridwave && p.mode != RT_MODE_PATHTRACE && p.max_depth > 0) return launch_gridwave(c, stream, A);
         return launch_blockwave(c, stream, A, accumulate_only);
     }
 
     // persistent grid: as many workgroups as the chip holds at once
-    bool lds = c->sv.image_bytes <= kMaxLdsImage;
-    size_t lds_bytes = lds ? (size_t)c->sv.image_bytes : 0;
+    bool lds = c->sv.lds_bytes <= kMaxLdsImage;
+    size_t lds_bytes = lds ? (size_t)c->sv.lds_bytes : 0;
     const int kmode = p.mode == RT_MODE_PATHTRACE ? 1 : 0;
     using KernelFn = void (*)(SceneView, RenderArgs);
     static const KernelFn table[2][2][2] = {
@@ -1800,15 +1814,6 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         for (double v : sph) regular = regular && in_window(v);
         sv.regular = regular ? 1 : 0;
     }
-    int off = 0;
-    sv.off_nodes = off; off = align16(off + sv.n_nodes * kNodeBytes);
-    sv.off_sph = off;   off = align16(off + (int)sph.size() * 8);
-    sv.off_tri = off;   off = align16(off + (int)tri.size() * 8);
-    sv.off_cyl = off;   off = align16(off + (int)cyl.size() * 8);
-    sv.off_gid_sph = off; off = align16(off + (int)gid_sph.size() * 4);
-    sv.off_gid_tri = off; off = align16(off + (int)gid_tri.size() * 4);
-    sv.off_gid_cyl = off; off = align16(off + (int)gid_cyl.size() * 4);
-    sv.off_ref = off;     off = align16(off + s->n_prims * 4);
     rt::FilterBVH fb;
     rt::build_filter_bvh(s, s->use_bvh ? &bvh : nullptr, fb);
     // scale cap: b * (1/d) with |1/d| <= 2^60 must stay finite in fp32 (closest_hit_fbvh)
@@ -1816,11 +1821,36 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sv.fbvh_ok = fb.ok ? 1 : 0;
     sv.n_fnodes = fb.n_nodes;
     sv.scene_scale = fb.scene_scale;
+    // Image layout: first what every ray of the filter-BVH traversal touches (staged into LDS), then the
+    // reference tree and the linear-scan table, which that traversal only reads for the rare rays it
+    // hands to the exact walk (from the global copy).  The other traversal modes stage everything.
+    int off = 0;
     if (fb.ok) {
         sv.off_fnodes = off;   off = align16(off + fb.n_nodes * kFNodeBytes);
-        sv.off_leafprim = off; off = align16(off + s->n_prims * 16);
+        sv.off_leafprim = off; off = align16(off + s->n_prims * kLeafBytes);
     }
+    sv.off_sph = off;   off = align16(off + (int)sph.size() * 8);
+    sv.off_tri = off;   off = align16(off + (int)tri.size() * 8);
+    sv.off_cyl = off;   off = align16(off + (int)cyl.size() * 8);
+    sv.off_gid_sph = off; off = align16(off + (int)gid_sph.size() * 4);
+    sv.off_gid_tri = off; off = align16(off + (int)gid_tri.size() * 4);
+    sv.off_gid_cyl = off; off = align16(off + (int)gid_cyl.size() * 4);
+    sv.off_matidx = off;  off = align16(off + s->n_prims * 4);
+    const int mat_bytes = align16(s->n_materials * (int)sizeof(DMaterial));
+    sv.mat_staged = off + mat_bytes <= kMaxLdsImage ? 1 : 0;  // clutter_500: 500 materials = 48 KB do not fit
+    if (sv.mat_staged) {
+        sv.off_mat = off;
+        off += mat_bytes;
+    }
+    sv.lds_bytes = std::max(off, 16);
+    if (!sv.mat_staged) {
+        sv.off_mat = off;
+        off += mat_bytes;
+    }
+    sv.off_nodes = off; off = align16(off + sv.n_nodes * kNodeBytes);
+    sv.off_ref = off;   off = align16(off + s->n_prims * 4);
     sv.image_bytes = std::max(off, 16);
+    if (!(fb.ok && c->traversal == 3 && c->wavefront)) sv.lds_bytes = sv.image_bytes;  // the per-pixel kernel walks the reference tree
     // Culling margin per node (closest_hit_fast<kCull>): absolute slack of 1e-6 of the box's size and
     // position, or +inf when some primitive below the node is not contained in its reference box
     // (cylinders whose axis is not exactly +Y, src/Cylinder.cpp:131-137): such nodes are never culled.
@@ -1878,8 +1908,11 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             std::memcpy(n + 32, links, 64);
         }
         for (int k = 0; k < s->n_prims; ++k) {
-            int rec[4] = {ref_of_gid[fb.leaf_prim[(size_t)k * 4]], fb.leaf_prim[(size_t)k * 4 + 1], fb.leaf_prim[(size_t)k * 4 + 2], 0};
-            std::memcpy(image.data() + sv.off_leafprim + (size_t)k * 16, rec, 16);
+            const int gate = fb.leaf_prim[(size_t)k * 4 + 1];  // reference node whose box gates the primitive, or -1
+            int rec[4] = {ref_of_gid[fb.leaf_prim[(size_t)k * 4]], gate, fb.leaf_prim[(size_t)k * 4 + 2], 0};
+            unsigned char* dst = image.data() + sv.off_leafprim + (size_t)k * kLeafBytes;
+            std::memcpy(dst, rec, 16);
+            if (gate >= 0) std::memcpy(dst + 16, &bvh.box[(size_t)gate * 6], 48);
         }
     }
 
@@ -1925,6 +1958,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         else texels.insert(texels.end(), t.rgb, t.rgb + n);
     }
 
+    if (s->n_prims) std::memcpy(image.data() + sv.off_matidx, mat_of_gid.data(), (size_t)s->n_prims * 4);
+    if (s->n_materials) std::memcpy(image.data() + sv.off_mat, mats.data(), (size_t)s->n_materials * sizeof(DMaterial));
     int rc;
     if ((rc = upload(&c->d_image, image)) != RT_OK) return rc;
     if ((rc = upload(&c->d_materials, mats)) != RT_OK) return rc;
