@@ -1850,6 +1850,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sv.off_nodes = off; off = align16(off + sv.n_nodes * kNodeBytes);
     sv.off_ref = off;   off = align16(off + s->n_prims * 4);
     sv.image_bytes = std::max(off, 16);
+    if (std::getenv("RT_WF_DEBUG"))
+        std::fprintf(stderr, "[scene] %d prims, %d filter nodes (%d B), leaf records %d B, primitives %d B, materials %d B (%s), staged %d B of %d B\n",
+                     s->n_prims, fb.n_nodes, fb.n_nodes * kFNodeBytes, s->n_prims * kLeafBytes, sv.off_gid_sph - sv.off_sph, mat_bytes,
+                     sv.mat_staged ? "staged" : "global", sv.lds_bytes, sv.image_bytes);
     if (!(fb.ok && c->traversal == 3 && c->wavefront)) sv.lds_bytes = sv.image_bytes;  // the per-pixel kernel walks the reference tree
     // Culling margin per node (closest_hit_fast<kCull>): absolute slack of 1e-6 of the box's size and
     // position, or +inf when some primitive below the node is not contained in its reference box
