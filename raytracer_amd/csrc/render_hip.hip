@@ -62,7 +62,10 @@ constexpr int kBlock = 512;          // threads per workgroup (per-pixel kernel)
 #define RT_TRACE_BLOCK 1024
 #endif
 constexpr int kTraceBlock = RT_TRACE_BLOCK;  // threads per workgroup of the frame kernels: one LDS scene image per 16 waves
-constexpr int kFusedBlock = 768;  // fused Whitted kernels: 168 VGPRs per lane (428 B of scratch instead of 604 B) beat a fourth wave per SIMD
+#ifndef RT_FUSED_BLOCK
+#define RT_FUSED_BLOCK 768
+#endif
+constexpr int kFusedBlock = RT_FUSED_BLOCK;  // fused Whitted kernels: 168 VGPRs per lane (428 B of scratch instead of 604 B) beat a fourth wave per SIMD
 constexpr int kMaxLdsImage = 150 * 1024;
 constexpr int kNF = 26;              // doubles per frame
 constexpr int kMaxDepthLimit = 64;
