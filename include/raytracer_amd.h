@@ -151,7 +151,9 @@ typedef struct rt_params {
 typedef struct rt_stats {
     uint64_t rays;         /* closest-hit queries traced by the last render (= Scene::intersect
                               calls the reference would make, src/Scene.cpp:63)                */
-    uint64_t box_tests;    /* BoundingBox::intersect evaluations actually executed            */
+    uint64_t box_tests;    /* BoundingBox::intersect evaluations actually executed (0 for the
+                            * default filter-BVH traversal unless built with -DRT_FBVH_COUNTS=1;
+                            * RT_TRAVERSAL=walk / cull always count)                            */
     uint64_t prim_tests;   /* primitive intersect evaluations actually executed               */
     uint64_t sphere_tests; /* ... of which Sphere::intersect                                   */
     uint64_t triangle_tests; /* ... Triangle::intersect                                        */

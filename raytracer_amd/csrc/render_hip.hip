@@ -379,12 +379,22 @@ typedef float F2 __attribute__((ext_vector_type(2)));
 #ifndef RT_PK_SLAB
 #define RT_PK_SLAB 0  // v_pk_fma_f32 form measured 4 % slower (pairs of broadcast operands cost 6 more VGPRs)
 #endif
+// Box / primitive test counters of the filter-BVH traversal: off in the production build (one VALU
+// instruction per walk step and four live VGPRs; rt_stats then reports rays only for this traversal --
+// the walk / cull traversals always count).  -DRT_FBVH_COUNTS=1 turns them on.
+#ifndef RT_FBVH_COUNTS
+#define RT_FBVH_COUNTS 0
+#endif
 template <bool kAny, typename P>
 RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tally, double t_limit = 0.0) {
     const double reach = 4.0 * sv.scene_scale;
     bool eligible = sv.fbvh_ok && sv.regular && ray_regular(o, d) && fabs(d.x) >= 0x1p-60 && fabs(d.y) >= 0x1p-60 &&
                     fabs(d.z) >= 0x1p-60 && fabs(o.x) <= reach && fabs(o.y) <= reach && fabs(o.z) <= reach;
-    if (!eligible) return closest_hit_fast<false, kAny>(sv.image, sv, o, d, tally, t_limit);  // reference nodes: global copy only
+    if (!eligible) {  // reference nodes: global copy only
+        if (RT_FBVH_COUNTS) return closest_hit_fast<false, kAny>(sv.image, sv, o, d, tally, t_limit);
+        Tally unused = {0, 0, 0, 0, 0};
+        return closest_hit_fast<false, kAny>(sv.image, sv, o, d, unused, t_limit);
+    }
     const double a = dot(d, d);
     const double two_a = 2.0 * a;
     const double r2a = refine_rcp(two_a);
@@ -415,7 +425,7 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
             const unsigned char* np = img + cur;
             float4 b0 = *(const float4*)np, b1 = *(const float4*)(np + 16);  // lo.x hi.x lo.y hi.y | lo.z hi.z first count
             int2 lk = *(const int2*)(np + link_off);
-            ++tally.box;
+            if (RT_FBVH_COUNTS) ++tally.box;
             // both planes of an axis in one packed FMA (v_pk_fma_f32)
 #if RT_PK_SLAB
             const F2 tx = __builtin_elementwise_fma(F2{b0.x, b0.y}, F2{rix, rix}, F2{nox, nox});
@@ -445,7 +455,7 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
             if (lp.y >= 0) {
                 const double* nb = (const double*)(rec + 16);
                 double t_enter;
-                ++tally.box;
+                if (RT_FBVH_COUNTS) ++tally.box;
                 if (!box_hit_regular(nb, o, d, r, t_enter)) continue;
             }
             int ref = lp.x;
@@ -454,13 +464,13 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
             int part = 0;
             bool ok;
             if (type == RT_SPHERE) {
-                ++tally.sph;
+                if (RT_FBVH_COUNTS) ++tally.sph;
                 ok = sphere_t_shared(sph + idx * kSphereDoubles, o, d, a, two_a, r2a, t);
             } else if (type == RT_TRIANGLE) {
-                ++tally.tri;
+                if (RT_FBVH_COUNTS) ++tally.tri;
                 ok = triangle_t(tri + idx * kTriDoubles, o, d, t);
             } else {
-                ++tally.cyl;
+                if (RT_FBVH_COUNTS) ++tally.cyl;
                 ok = cylinder_t(cyl + idx * kCylDoubles, o, d, t, part);
             }
             if (!ok) continue;
