@@ -375,10 +375,6 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
 // ray's octant through precomputed links (no stack), culled against the best t so far.  Leaves: the
 // reference's own two fp64 tests -- the gate box (BoundingBox::intersect on the BVHNode that holds
 // the primitive) and the primitive -- and the reference's tie rule via the DFS-order key.
-typedef float F2 __attribute__((ext_vector_type(2)));
-#ifndef RT_PK_SLAB
-#define RT_PK_SLAB 0  // v_pk_fma_f32 form measured 4 % slower (pairs of broadcast operands cost 6 more VGPRs)
-#endif
 // Box / primitive test counters of the filter-BVH traversal: off in the production build (one VALU
 // instruction per walk step and four live VGPRs; rt_stats then reports rays only for this traversal --
 // the walk / cull traversals always count).  -DRT_FBVH_COUNTS=1 turns them on.
@@ -418,36 +414,31 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
     // ray (1e-5 t)], written as max(enter, 0) * (1 - 2.1 s) <= exit: the same for enter > 0, and for
     // enter <= 0 both reduce to exit >= 0.
     const float kShrink = 1.0f - 4.2e-5f;
-    int cur = sv.off_fnodes;  // byte offset of the node record in the image; < 0: done
+    // `cur`: byte offset of a node record in the image; -1: done; < -1: a leaf to process,
+    // -2 - (first record << 2 | records), which is what a leaf's "pass" links hold -- so the walk loop has
+    // one exit test and never reads a leaf count.
+    int cur = sv.off_fnodes;
     for (;;) {
-        int lf = 0, lc = 0;
+        int after = -1;  // where the walk goes on after a leaf: the leaf's "fail" link
         while (cur >= 0) {
             const unsigned char* np = img + cur;
-            float4 b0 = *(const float4*)np, b1 = *(const float4*)(np + 16);  // lo.x hi.x lo.y hi.y | lo.z hi.z first count
-            int2 lk = *(const int2*)(np + link_off);
+            const float4 b0 = *(const float4*)np;              // lo.x hi.x lo.y hi.y
+            const float2 b1 = *(const float2*)(np + 16);       // lo.z hi.z
+            const int2 lk = *(const int2*)(np + link_off);
             if (RT_FBVH_COUNTS) ++tally.box;
-            // both planes of an axis in one packed FMA (v_pk_fma_f32)
-#if RT_PK_SLAB
-            const F2 tx = __builtin_elementwise_fma(F2{b0.x, b0.y}, F2{rix, rix}, F2{nox, nox});
-            const F2 ty = __builtin_elementwise_fma(F2{b0.z, b0.w}, F2{riy, riy}, F2{noy, noy});
-            const F2 tz = __builtin_elementwise_fma(F2{b1.x, b1.y}, F2{riz, riz}, F2{noz, noz});
-#else
-            const F2 tx = F2{__builtin_fmaf(b0.x, rix, nox), __builtin_fmaf(b0.y, rix, nox)};
-            const F2 ty = F2{__builtin_fmaf(b0.z, riy, noy), __builtin_fmaf(b0.w, riy, noy)};
-            const F2 tz = F2{__builtin_fmaf(b1.x, riz, noz), __builtin_fmaf(b1.y, riz, noz)};
-#endif
-            float enter = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
-            float exit = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+            const float x0 = __builtin_fmaf(b0.x, rix, nox), x1 = __builtin_fmaf(b0.y, rix, nox);
+            const float y0 = __builtin_fmaf(b0.z, riy, noy), y1 = __builtin_fmaf(b0.w, riy, noy);
+            const float z0 = __builtin_fmaf(b1.x, riz, noz), z1 = __builtin_fmaf(b1.y, riz, noz);
+            float enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+            float exit = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
             bool fail = fmaxf(enter, 0.f) * kShrink > fminf(exit, bound);  // a NaN passes
-            int cnt = __float_as_int(b1.w);
+            after = lk.y;
             cur = fail ? lk.y : lk.x;
-            if (!fail && cnt > 0) {
-                lf = __float_as_int(b1.z);
-                lc = cnt;
-                break;
-            }
         }
-        if (lc == 0) break;
+        if (cur == -1) break;
+        const int code = -2 - cur;
+        const int lf = code >> 2, lc = code & 3;
+        cur = after;
 #pragma unroll 1
         for (int k = 0; k < lc; ++k) {
             const unsigned char* rec = img + sv.off_leafprim + (lf + k) * kLeafBytes;
@@ -1921,6 +1912,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             for (int k = 0; k < 16; ++k) {
                 int to = fb.links[(size_t)i * 16 + k];
                 links[k] = to < 0 ? -1 : sv.off_fnodes + to * kFNodeBytes;
+                // a leaf's "pass" link names its records instead (closest_hit_fbvh); the walk then goes on
+                // along the "fail" link, which for a leaf is the same node
+                if (fb.leaf_count[i] > 0 && (k & 1) == 0) links[k] = -2 - ((fb.leaf_first[i] << 2) | fb.leaf_count[i]);
             }
             std::memcpy(n + 32, links, 64);
         }
