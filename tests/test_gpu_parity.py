@@ -215,6 +215,38 @@ def test_random_soup_with_mirrors_and_glass(renderer, seed):
         assert_frame_parity(rgb, hit, st, orgb, ohit, cnt)
 
 
+def large_soup(seed=7, n_sph=1500, n_tri=300, n_cyl=100):
+    """1900 primitives: the staged part of the scene image (filter nodes, leaf records, geometry) is
+    several times the 150 KB that fit in LDS, so every kernel reads the image from HBM."""
+    rng = np.random.default_rng(seed)
+    types, geom = scene_util.random_prims(rng, n_sph, n_tri, n_cyl, extent=10.0)
+    mats = [scene_util.default_material(),
+            scene_util.default_material(diffuse=(0.2, 0.3, 0.9), reflective=1, reflectivity=0.6),
+            scene_util.default_material(diffuse=(0.9, 0.9, 0.9), refractive=1, ior=1.5),
+            scene_util.default_material(diffuse=(0.5, 0.9, 0.4), reflective=1, reflectivity=0.3, refractive=1, ior=1.33)]
+    pm = rng.integers(0, len(mats), len(types)).astype(np.int32)
+    lights = [scene_util.point_light((0, 25, -10)), scene_util.point_light((15, 6, 15), (0.5, 0.4, 0.3)),
+              scene_util.area_light((0, 14, 0), (0, -1, 0), (1, 0, 0), (0, 0, 1), 2, 2)]
+    cam = scene_util.look_at((0, 3, -32), (0, 0, 0))
+    return types, geom, mats, pm, lights, cam
+
+
+@pytest.mark.parametrize("which", ["renderer", "renderer_block", "renderer_grid", "renderer_levels", "renderer_mega"])
+def test_scene_too_large_for_lds(request, which):
+    """The non-staged form of every pipeline (scene image in HBM), both tie rules."""
+    r = request.getfixturevalue(which)
+    types, geom, mats, pm, lights, cam = large_soup()
+    for use_bvh in ((0, 1) if which == "renderer" else (1,)):
+        s = scene_util.SyntheticScene(types, geom, materials=mats, lights=lights, prim_material=pm, use_bvh=use_bvh)
+        P = scene_util.make_params(96, 64, max_depth=5)
+        r.upload(s.desc); r.set_camera(cam); r.set_params(P)
+        rgb, hit = r.render()
+        st = r.stats()
+        assert st.scene_in_lds == 0
+        orgb, ohit, cnt, _ = oracle_lib.render(s.desc, cam, P)
+        assert_frame_parity(rgb, hit, st, orgb, ohit, cnt)
+
+
 def test_culling_never_changes_a_hit_on_loose_cylinder_boxes(renderer, renderer_walk):
     """Cylinders with arbitrary axes stick out of the boxes the reference gives them
     (src/Cylinder.cpp:131-137); nodes above them must never be culled by entry distance."""

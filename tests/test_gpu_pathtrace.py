@@ -59,6 +59,20 @@ def test_other_pipelines_path_trace_the_same_image(request, which):
     assert_pt_parity(*gpu_and_oracle(r, sf, P))
 
 
+def test_scene_too_large_for_lds_path_traced(renderer):
+    """1900 primitives: the kernels read the scene image from HBM instead of a staged LDS copy."""
+    from tests.test_gpu_parity import large_soup
+    types, geom, mats, pm, lights, cam = large_soup()
+    s = scene_util.SyntheticScene(types, geom, materials=mats, lights=lights, prim_material=pm, use_bvh=1)
+    P = scene_util.make_params(96, 64, mode=rt.RT_MODE_PATHTRACE, max_depth=5, pixel_samples=4, light_samples=2)
+    renderer.upload(s.desc); renderer.set_camera(cam); renderer.set_params(P)
+    rgb, _ = renderer.render(want_hit=False)
+    st = renderer.stats()
+    assert st.scene_in_lds == 0
+    orgb, _, cnt, _ = oracle_lib.render(s.desc, cam, P, want_hit=False)
+    assert_pt_parity(rgb, st, orgb, cnt)
+
+
 def test_many_strata_in_several_passes(renderer, monkeypatch):
     """A node budget small enough to force several passes over the strata: sums must not change."""
     sf = scene_util.load("pathtrace", 64, 48)
