@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="clutter_500_4k", choices=["clutter_500_4k", "pathtrace_1080p"])
     ap.add_argument("--spp", type=int, default=16, help="path trace: strata per step")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="Whitted: frames in flight, one render context + stream each (default 4)")
+    ap.add_argument("--workgroups", type=int, default=-1,
+                    help="workgroups per context (default: 0 = fill the chip when 1 frame is in flight, else 128 / 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,16 +91,11 @@ def main():
     os.environ["RT_TRAVERSAL"] = "walk"
     rw = rt.Renderer(local_rank)
     os.environ.pop("RT_TRAVERSAL")
-    r = rt.Renderer(local_rank)
-    r.upload(desc)
-    r.set_camera(sf.camera)
     P = rt.copy_params(base)
     if pathtrace:
         P.sample_begin, P.sample_end = rtd.strata_range(rank, world, base.pixel_samples)
     else:
         P.band_rank, P.band_world = rank, world
-    r.set_params(P)
-    rows = r.local_rows
     rw.upload(desc)
     rw.set_camera(sf.camera)
     rw.set_params(P)
@@ -104,43 +103,73 @@ def main():
     ref_st = rw.stats()
     ref_counts = [ref_st.rays, ref_st.box_tests, ref_st.sphere_tests, ref_st.triangle_tests, ref_st.cylinder_tests]
     rw.close()
-    stream = torch.cuda.current_stream().cuda_stream
 
-    # Frames are pipelined two deep: the collective of frame k (RCCL stream) overlaps the kernels of frame
-    # k+1 (this stream).  Whitted frames travel as PPM bytes (rt_quantize_device), path-trace passes as
-    # fp64 partial sums (the division / tone map / gamma come after the reduction).
+    # Frames in flight.  Whitted: F render contexts of G workgroups each, one stream per context, frames
+    # dealt round-robin -- the frames share the chip's 256 CUs, which hides the per-level latency of a
+    # frame's thin levels (and of a rank's 1/N share of a frame); the gather of frame k (RCCL's stream)
+    # overlaps the kernels of the frames after it.  Whitted frames travel as PPM bytes
+    # (rt_quantize_device), path-trace passes as fp64 partial sums (the division / tone map / gamma come
+    # after the reduction); path tracing keeps one context and two buffers.
+    F = 1 if pathtrace else (args.in_flight if args.in_flight > 0 else 4)
+    streams = None
+    while F > 1 and streams is None:
+        try:
+            streams = rtd.concurrent_streams(F, dev)  # streams that do not share a hardware queue (measured)
+        except RuntimeError:
+            F -= 1
+    G = args.workgroups if args.workgroups >= 0 else (0 if F == 1 else (128 if world <= 2 else 64))
+    rs = []
+    for _ in range(F):
+        r = rt.Renderer(local_rank)
+        r.upload(desc)
+        r.set_camera(sf.camera)
+        r.set_params(P)
+        r.set_workgroups(G)
+        rs.append(r)
+    rows = rs[0].local_rows
+    depth = max(F, 2)  # slots; a slot is free again once its frame was completed
     if pathtrace:
-        pipe = rtd.AccumulatorPipeline(world, H * W * 3, dev)
+        pipe = rtd.AccumulatorPipeline(world, H * W * 3, dev, depth=depth)
     else:
-        pipe = rtd.FramePipeline(rank, world, H, W, dev, band_rows=P.band_rows)
+        pipe = rtd.FramePipeline(rank, world, H, W, dev, band_rows=P.band_rows, depth=depth, streams=streams)
         n_mine = rows * W * 3
 
+    import contextlib
+
+    def on_stream(k):
+        s = None if pathtrace else pipe.stream(k)
+        return torch.cuda.stream(s) if s is not None else contextlib.nullcontext()
+
     def enqueue(k, ev=None):
-        if pathtrace:
-            accum = pipe.target(k)
-            if ev: ev[0].record()
-            r.accumulate_device(accum.data_ptr(), stream=stream)
-            if ev: ev[1].record()
-        else:
-            rgb, u8 = pipe.target(k)
-            if ev: ev[0].record()
-            r.render_device(rgb.data_ptr(), None, stream=stream)
-            if ev: ev[1].record()
-            r.quantize_device(rgb.data_ptr(), n_mine, u8.data_ptr(), stream=stream)
-        pipe.submit(k)
+        r = rs[k % F]
+        with on_stream(k):
+            stream = torch.cuda.current_stream().cuda_stream
+            if pathtrace:
+                accum = pipe.target(k)
+                if ev: ev[0].record()
+                r.accumulate_device(accum.data_ptr(), stream=stream)
+                if ev: ev[1].record()
+            else:
+                rgb, u8 = pipe.target(k)
+                if ev: ev[0].record()
+                r.render_device(rgb.data_ptr(), None, stream=stream)
+                if ev: ev[1].record()
+                r.quantize_device(rgb.data_ptr(), n_mine, u8.data_ptr(), stream=stream)
+            pipe.submit(k)
 
     def finish(k):
-        out = pipe.complete(k)
-        if pathtrace and rank == 0:
-            r.resolve_device(out.data_ptr(), H * W, stream=stream)
+        with on_stream(k):
+            out = pipe.complete(k)
+            if pathtrace and rank == 0:
+                rs[0].resolve_device(out.data_ptr(), H * W, stream=torch.cuda.current_stream().cuda_stream)
 
     def run(n, events=None):
         for k in range(n):
             enqueue(k, events[k] if events else None)
-            if k > 0:
-                finish(k - 1)
-        if n > 0:
-            finish(n - 1)
+            if k >= depth - 1:
+                finish(k - (depth - 1))  # frees the slot frame k + 1 renders into
+        for k in range(max(n - (depth - 1), 0), n):
+            finish(k)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -148,6 +177,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    run(F)  # every context's first frame sizes its node store (synchronous): not a warm-up step
+    sync_all()
     run(args.warmup)
     sync_all()
     # per-launch duration of the render kernels: HIP events on the stream they are launched on
@@ -157,7 +188,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in events]
-    st = r.stats()
+    st = rs[(args.steps - 1) % F].stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     assert st.rays == ref_counts[0], "the production traversal must trace exactly the reference's rays"
@@ -177,7 +208,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays * args.steps / elapsed / 1e6
         alg_ops = OPS_BOX * boxes + OPS_SPHERE * sph + OPS_TRI * tri + OPS_CYL * cyl  # per frame, all ranks
-        achieved = alg_ops / world / (k_ms * 1e-3) / 1e12  # per GPU: ops of one launch / its duration
+        # per GPU: ops of one launch / its duration.  With F launches in flight on F streams a launch has a
+        # share of the chip only, so the chip's rate is the ops of all launches of the timed region over
+        # that region (a lower bound: it includes the gaps between kernels).
+        achieved = alg_ops / world / ((k_ms if F == 1 else ms_per_step) * 1e-3) / 1e12
         line = {
             "metric": "Mrays/s" if not pathtrace else "spp/s",
             "value": mrays if not pathtrace else (base.pixel_samples / (elapsed / args.steps)),
@@ -194,7 +228,7 @@ def main():
                          "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
                          "kernel": ("bw_kernel + bw_accumulate_path_kernel per batch of strata (per depth: trace, shadow, shade; combine)" if pathtrace
                                     else "fw_roots_kernel (level 0) + fw_kernel (depth >= 1: fused trace/shadow/shade per level, combine, tone map)"),
-                         "kernel_ms": k_ms,
+                         "kernel_ms": k_ms, "launches_in_flight": F, "workgroups_per_launch": G or "all",
                          "ops_per_ray": alg_ops / max(rays, 1.0),
                          "reference_box_tests_per_ray": boxes / max(rays, 1.0),
                          # counters of the production traversal are compiled out (-DRT_FBVH_COUNTS=1 turns them on;

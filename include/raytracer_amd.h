@@ -234,6 +234,15 @@ int rt_pathtrace_accumulate_device(rt_context* ctx, void* stream, double* accum_
  * the file. */
 int rt_quantize_device(rt_context* ctx, void* stream, const double* rgb_dev, int64_t n_values, uint8_t* out_dev);
 
+/* Caps the grid of the persistent render kernels at n_workgroups (0 = as many as the chip holds, the
+ * default; the environment variable RT_WORKGROUPS sets the initial value).  For callers that keep
+ * several frames in flight on one GPU -- one context and one stream per frame, e.g. 4 contexts of 64
+ * workgroups: the frames then share the chip's 256 CUs instead of queueing behind one another, which
+ * hides the per-level latency of thin frames (a rank's 1/8 share of a 4K frame).  Results do not
+ * depend on it.  No counterpart in the reference (its loop is one OpenMP parallel-for,
+ * RayTracer.cpp:213-236). */
+int rt_set_workgroups(rt_context* ctx, int32_t n_workgroups);
+
 /* RayTracer.cpp:301-315 (path trace) on n_pixels pixels of a device buffer in place:
  * / pixelSamples, tone map, * exposure, pow(1/2.2), clamp. */
 int rt_pathtrace_resolve_device(rt_context* ctx, void* stream, double* accum_dev,

@@ -109,6 +109,10 @@ class Renderer:
         capi.check(self._lib.rt_pathtrace_resolve_device(self._h, stream, accum_ptr, n_pixels),
                    "rt_pathtrace_resolve_device")
 
+    def set_workgroups(self, n):
+        """Caps the persistent kernels' grid (0 = fill the chip): for several contexts rendering at once."""
+        capi.check(self._lib.rt_set_workgroups(self._h, int(n)), "rt_set_workgroups")
+
     def quantize_device(self, rgb_ptr, n_values, out_ptr, stream=None):
         """int(255.999 * c) per component (the PPM payload) from one device buffer into another."""
         capi.check(self._lib.rt_quantize_device(self._h, stream, rgb_ptr, n_values, out_ptr), "rt_quantize_device")

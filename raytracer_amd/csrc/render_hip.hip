@@ -1481,6 +1481,7 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
 struct rt_context {
     int device = 0;
     int n_cus = 0;
+    int max_workgroups = 0;  // cap on a persistent kernel's grid (0: as many as the chip holds), RT_WORKGROUPS / rt_set_workgroups
     bool have_scene = false, have_camera = false, have_params = false;
     SceneView sv;
     rt_camera cam;
@@ -1717,6 +1718,7 @@ int rt_create(rt_context** out, int device) {
     c->gridwave = pipe && std::strcmp(pipe, "grid") == 0;
     if (const char* e = std::getenv("RT_SPLIT_ROOTS")) c->split_roots = std::atoi(e) != 0;
     c->n_cus = prop.multiProcessorCount;
+    if (const char* e = std::getenv("RT_WORKGROUPS")) c->max_workgroups = std::max(0, std::atoi(e));
     std::memset(&c->sv, 0, sizeof c->sv);
     hipError_t a = hipMalloc((void**)&c->d_ticket, sizeof(unsigned int));
     hipError_t b = hipMalloc((void**)&c->d_counters, (size_t)kCounterSlots * kCounterRow * sizeof(unsigned long long));
@@ -2055,6 +2057,16 @@ int rt_pathtrace_resolve_device(rt_context* c, void* stream, double* accum_dev, 
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, accum_dev, (long long)n_pixels,
                        c->params.pixel_samples, c->params.tonemap, c->params.exposure);
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_set_workgroups(rt_context* c, int32_t n_workgroups) {
+    if (!c) return rt::set_error(RT_ERR_INVALID, "rt_set_workgroups: null context");
+    if (n_workgroups < 0) return rt::set_error(RT_ERR_INVALID, "rt_set_workgroups: %d", n_workgroups);
+    if (c->max_workgroups != n_workgroups) {
+        c->max_workgroups = n_workgroups;
+        ++c->generation;  // arena sizes were calibrated for the old grid
+    }
     return RT_OK;
 }
 

@@ -28,6 +28,45 @@ def strata_range(rank, world, n_strata):
     return (lo, hi) if hi > lo else (n_strata, n_strata)
 
 
+def concurrent_streams(n, device, candidates=16, spin_cycles=2_000_000):
+    """n torch streams on `device` whose kernels really run side by side.
+
+    HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams
+    that share a queue serialize; which streams share one is not visible through the API and is not
+    simply creation order.  So this measures it: a candidate joins the set if spin kernels on the set
+    plus the candidate take the time of one spin, not two.  Raises if fewer than n can be found."""
+    if n <= 1:
+        return [torch.cuda.current_stream(device)] if n == 1 else []
+    pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+
+    def spin_ms(streams):
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        first = torch.cuda.current_stream(device)
+        for s in streams:
+            s.wait_stream(first)
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(spin_cycles)
+        for s in streams:
+            first.wait_stream(s)
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b)
+
+    spin_ms(pool[:1])  # warm-up
+    one = min(spin_ms(pool[:1]) for _ in range(2))
+    chosen = [pool[0]]
+    for c in pool[1:]:
+        if len(chosen) == n:
+            break
+        if min(spin_ms(chosen + [c]) for _ in range(2)) < 1.5 * one:
+            chosen.append(c)
+    if len(chosen) < n:
+        raise RuntimeError(f"only {len(chosen)} of {n} streams run concurrently on {device} (GPU_MAX_HW_QUEUES?)")
+    return chosen
+
+
 class BandGatherer:
     """Gathers every rank's compact band buffer on rank 0 and scatters the rows into the frame."""
 
@@ -59,13 +98,20 @@ class BandGatherer:
 
 class FramePipeline:
     """Whitted frames of a multi-GPU job, pipelined: every rank renders its bands of frame k into one of
-    `depth` device buffers, converts them to PPM bytes (rt_quantize_device: an eighth of the fp64 data), and
-    the gather of those bytes to rank 0 runs asynchronously (RCCL's own stream, xGMI) while frame k+1 is
-    being rendered.  complete(k) makes the current stream wait for frame k's gather and scatters its rows
-    into `frame` (rank 0: uint8 [H, W, 3], row 0 = bottom row)."""
+    `depth` slots (device buffers), converts them to PPM bytes (rt_quantize_device: an eighth of the fp64
+    data), and the gather of those bytes to rank 0 runs asynchronously (RCCL's own stream, xGMI) while later
+    frames are being rendered.  complete(k) makes the slot's stream wait for frame k's gather and scatters
+    its rows into that slot's frame (rank 0: uint8 [H, W, 3], row 0 = bottom row).
 
-    def __init__(self, rank, world, height, width, device, band_rows=8, depth=2):
+    `streams` (optional, one per slot): frames in flight on different streams -- with one render context
+    per slot (rt_set_workgroups) the frames share the chip instead of queueing; stream(k) is the one to
+    make current (torch.cuda.stream) around frame k's enqueue / submit / complete.  Without it every
+    slot uses the current stream."""
+
+    def __init__(self, rank, world, height, width, device, band_rows=8, depth=2, streams=None):
         self.rank, self.world, self.H, self.W, self.depth = rank, world, height, width, depth
+        assert streams is None or len(streams) == depth
+        self.streams = streams
         self.slot_rows = max_band_rows(world, height, band_rows)
         n = self.slot_rows * width * 3
         self.rgb = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(depth)]
@@ -75,10 +121,9 @@ class FramePipeline:
         self.slots = None
         self.index = None
         if rank == 0 and world > 1:
-            # one receive buffer per frame in flight, [world, slot_rows, W*3]; row H of `_frame` is a dump for
-            # the padding rows of ranks whose share is short, so that ONE index_copy_ assembles a frame
-            self._frame = torch.empty(height + 1, width * 3, dtype=torch.uint8, device=device)
-            self.frame = self._frame[:height].view(height, width, 3)
+            # per slot: one receive buffer [world, slot_rows, W*3] and one assembled frame; row H of a frame
+            # is a dump for the padding rows of ranks whose share is short, so that ONE index_copy_ assembles it
+            self._frame = [torch.empty(height + 1, width * 3, dtype=torch.uint8, device=device) for _ in range(depth)]
             self._recv = [torch.empty(world, self.slot_rows, width * 3, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.slots = [[self._recv[i][q].view(-1) for q in range(world)] for i in range(depth)]
             idx = torch.full((world, self.slot_rows), height, dtype=torch.long)
@@ -86,6 +131,10 @@ class FramePipeline:
                 rows = band_rows_of(q, world, height, band_rows)
                 idx[q, : len(rows)] = torch.tensor(rows, dtype=torch.long)
             self.index = idx.view(-1).to(device)
+
+    def stream(self, k):
+        """The stream frame k's work belongs on (None: the current one)."""
+        return self.streams[k % self.depth] if self.streams else None
 
     def target(self, k):
         """(fp64 render target, uint8 quantization target) of frame k."""
@@ -98,7 +147,8 @@ class FramePipeline:
             self.pending[i] = dist.gather(self.u8[i], self.slots[i] if self.rank == 0 else None, dst=0, async_op=True)
 
     def complete(self, k):
-        """Frame k is assembled on rank 0 once the current stream reaches this point."""
+        """Frame k is assembled on rank 0 once the current stream reaches this point.  Must be called
+        before the slot is used again (frame k + depth)."""
         i = k % self.depth
         if self.world == 1:  # one rank's compact buffer IS the frame (bands in order)
             self.frame = self.u8[i][: self.H * self.W * 3].view(self.H, self.W, 3)
@@ -108,7 +158,8 @@ class FramePipeline:
             work.wait()
         if self.rank != 0:
             return None
-        self._frame.index_copy_(0, self.index, self._recv[i].view(self.world * self.slot_rows, self.W * 3))
+        self._frame[i].index_copy_(0, self.index, self._recv[i].view(self.world * self.slot_rows, self.W * 3))
+        self.frame = self._frame[i][: self.H].view(self.H, self.W, 3)
         return self.frame
 
 

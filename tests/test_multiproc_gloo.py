@@ -52,6 +52,24 @@ def _worker(rank, world, port, q):
         fr = fp.complete(2)
         if rank == 0:
             out["pipeline_equal"] = ok and bool(np.array_equal(fr.numpy(), u8_full + 2))
+        # four frames in flight, the order bench.py issues them in: complete(k - depth) before slot reuse
+        fp4 = rtd.FramePipeline(rank, world, P.height, P.width, torch.device("cpu"), depth=4)
+        ok4, n_frames = True, 10
+        def check4(k):
+            fr = fp4.complete(k)
+            return rank != 0 or bool(np.array_equal(fr.numpy(), u8_full + k))
+        for k in range(n_frames):
+            if k >= 4:
+                ok4 = check4(k - 4) and ok4
+            assert fp4.stream(k) is None
+            _, u8_t = fp4.target(k)
+            mine8 = torch.from_numpy(np.ascontiguousarray(u8_full[rows] + k))
+            u8_t[: mine8.numel()] = mine8.reshape(-1)
+            fp4.submit(k)
+        for k in range(n_frames - 4, n_frames):
+            ok4 = check4(k) and ok4
+        if rank == 0:
+            out["pipeline4_equal"] = ok4
         ap = rtd.AccumulatorPipeline(world, 8, torch.device("cpu"))
         for k in range(3):
             ap.target(k).fill_(float(rank + 1 + k))
@@ -101,7 +119,7 @@ def test_two_ranks_reassemble_the_frame():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out["bands_equal"] and out["accum_close"] and out["resolved_close"]
-    assert out["pipeline_equal"] and out["accum_pipeline"]
+    assert out["pipeline_equal"] and out["pipeline4_equal"] and out["accum_pipeline"]
     assert out["ranges"] == [(2, 2), (0, 1), (2, 2), (1, 2)]
 
 
