@@ -132,7 +132,6 @@ def main():
         pipe = rtd.AccumulatorPipeline(world, H * W * 3, dev, depth=depth)
     else:
         pipe = rtd.FramePipeline(rank, world, H, W, dev, band_rows=P.band_rows, depth=depth, streams=streams)
-        n_mine = rows * W * 3
 
     import contextlib
 
@@ -150,11 +149,10 @@ def main():
                 r.accumulate_device(accum.data_ptr(), stream=stream)
                 if ev: ev[1].record()
             else:
-                rgb, u8 = pipe.target(k)
+                _, u8 = pipe.target(k)
                 if ev: ev[0].record()
-                r.render_device(rgb.data_ptr(), None, stream=stream)
+                r.render_device_u8(u8.data_ptr(), None, None, stream=stream)  # PPM bytes straight from the kernels
                 if ev: ev[1].record()
-                r.quantize_device(rgb.data_ptr(), n_mine, u8.data_ptr(), stream=stream)
             pipe.submit(k)
 
     def finish(k):

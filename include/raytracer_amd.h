@@ -234,6 +234,14 @@ int rt_pathtrace_accumulate_device(rt_context* ctx, void* stream, double* accum_
  * the file. */
 int rt_quantize_device(rt_context* ctx, void* stream, const double* rgb_dev, int64_t n_values, uint8_t* out_dev);
 
+/* rt_render_device with the PPM conversion fused into the kernels' pixel store (binary / phong modes):
+ * rgb8_dev receives int(255.999 * c) per component (RayTracer.cpp:359-362 applied to the clamped
+ * colour of :231-235), 3 bytes per pixel in the layout of rt_render_device's buffer; rgb_dev, if not
+ * null, also receives the fp64 frame.  A job that only writes / ships the PPM thereby skips the fp64
+ * frame (24 B per pixel written and read again by rt_quantize_device) and one kernel launch.
+ * Path-trace contexts are refused: their frames are sums until rt_pathtrace_resolve_device. */
+int rt_render_device_u8(rt_context* ctx, void* stream, uint8_t* rgb8_dev, double* rgb_dev, int32_t* hit_id_dev);
+
 /* Caps the grid of the persistent render kernels at n_workgroups (0 = as many as the chip holds, the
  * default; the environment variable RT_WORKGROUPS sets the initial value).  For callers that keep
  * several frames in flight on one GPU -- one context and one stream per frame, e.g. 4 contexts of 64

@@ -101,6 +101,10 @@ class Renderer:
     def render_device(self, rgb_ptr, hit_ptr=None, stream=None):
         capi.check(self._lib.rt_render_device(self._h, stream, rgb_ptr, hit_ptr), "rt_render_device")
 
+    def render_device_u8(self, rgb8_ptr, rgb_ptr=None, hit_ptr=None, stream=None):
+        """Whitted / binary frame as PPM bytes (and, optionally, the fp64 frame as well)."""
+        capi.check(self._lib.rt_render_device_u8(self._h, stream, rgb8_ptr, rgb_ptr, hit_ptr), "rt_render_device_u8")
+
     def accumulate_device(self, accum_ptr, stream=None):
         capi.check(self._lib.rt_pathtrace_accumulate_device(self._h, stream, accum_ptr),
                    "rt_pathtrace_accumulate_device")

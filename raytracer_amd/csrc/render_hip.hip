@@ -136,7 +136,8 @@ struct RenderArgs {
     unsigned int seed_lo, seed_hi;
     int accumulate_only;  // path trace: write raw sums
     // outputs / workspace
-    double* rgb;
+    double* rgb;              // fp64 frame (may be null when rgb8 is given: Whitted / binary only)
+    unsigned char* rgb8;      // or null: the PPM payload, int(255.999 * c) per component (RayTracer.cpp:359-362)
     int* hit_id;
     double* frames;           // [max_depth+1][kNF][n_threads]
     long long frame_stride;   // n_threads
@@ -738,6 +739,26 @@ RT_DEV double schlick(double cosTheta, double ior) {  // fresnelReflectance, Ray
     return r0 + (1.0 - r0) * (y2 * y2 * y);  // pow(y, 5.0)
 }
 
+// Final store of a Whitted / binary pixel (RayTracer.cpp:231-235 clamp, :359-362 PPM conversion): the fp64
+// frame, the PPM bytes, or both.  `c` is the tone-mapped, exposed colour.
+RT_DEV unsigned char ppm_byte(double c) {  // the same expression as quantize_kernel
+    int v = (int)(255.999 * c);
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+RT_DEV void store_pixel(const RenderArgs& A, long long p, D3 c) {
+    const double r = clamp01(c.x), g = clamp01(c.y), b = clamp01(c.z);
+    if (A.rgb) {
+        A.rgb[p * 3] = r;
+        A.rgb[p * 3 + 1] = g;
+        A.rgb[p * 3 + 2] = b;
+    }
+    if (A.rgb8) {
+        A.rgb8[p * 3] = ppm_byte(r);
+        A.rgb8[p * 3 + 1] = ppm_byte(g);
+        A.rgb8[p * 3 + 2] = ppm_byte(b);
+    }
+}
+
 RT_DEV D3 light_position(const DLight& Lt) {  // only PointLight overrides getPosition (Light.cpp:9-11)
     return Lt.type == RT_LIGHT_POINT ? ld3(Lt.position) : mk(0, 0, 0);
 }
@@ -746,10 +767,7 @@ template <typename P>
 RT_DEV void finish_pixel_whitted(const RenderArgs& A, Lane& L, D3 color) {
     color = tone_map(color, A.tonemap);
     color = color * A.exposure;
-    long long idx = ((long long)L.lrow * A.W + L.px) * 3;
-    A.rgb[idx] = clamp01(color.x);
-    A.rgb[idx + 1] = clamp01(color.y);
-    A.rgb[idx + 2] = clamp01(color.z);
+    store_pixel(A, (long long)L.lrow * A.W + L.px, color);
     L.kind = RAY_NONE;
 }
 
@@ -1404,8 +1422,7 @@ __global__ void resolve_kernel(double* buf, long long n_pixels, int pixel_sample
 __global__ void __launch_bounds__(256) quantize_kernel(const double* rgb, long long n, unsigned char* out) {
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        int v = (int)(255.999 * rgb[i]);
-        out[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        out[i] = ppm_byte(rgb[i]);
     }
 }
 
@@ -1586,7 +1603,8 @@ int upload(T** dst, const std::vector<T>& src) {
 #include "blockwave_host.inc"
 #include "gridwave_host.inc"
 
-int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_dev, bool accumulate_only) {
+int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_dev, bool accumulate_only,
+                  unsigned char* rgb8_dev = nullptr) {
     if (!c->have_scene || !c->have_camera || !c->have_params)
         return rt::set_error(RT_ERR_STATE, "render: scene, camera and params must be set first");
     const rt_params& p = c->params;
@@ -1625,6 +1643,7 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     A.seed_hi = (unsigned)(p.seed >> 32);
     A.accumulate_only = accumulate_only ? 1 : 0;
     A.rgb = rgb_dev;
+    A.rgb8 = rgb8_dev;
     A.hit_id = hit_dev;
     A.ticket = c->d_ticket;
     A.counters = c->d_counters;
@@ -2058,6 +2077,15 @@ int rt_pathtrace_resolve_device(rt_context* c, void* stream, double* accum_dev, 
                        c->params.pixel_samples, c->params.tonemap, c->params.exposure);
     HIP_TRY(hipGetLastError());
     return RT_OK;
+}
+
+int rt_render_device_u8(rt_context* c, void* stream, uint8_t* rgb8_dev, double* rgb_dev, int32_t* hit_id_dev) {
+    if (!c || !rgb8_dev) return rt::set_error(RT_ERR_INVALID, "rt_render_device_u8: null argument");
+    if (!c->have_params) return rt::set_error(RT_ERR_STATE, "rt_render_device_u8: params not set");
+    if (c->params.mode == RT_MODE_PATHTRACE)
+        return rt::set_error(RT_ERR_INVALID, "rt_render_device_u8: path-trace frames are sums until rt_pathtrace_resolve_device; "
+                                             "convert the resolved frame with rt_quantize_device");
+    return launch_render(c, (hipStream_t)stream, rgb_dev, hit_id_dev, false, rgb8_dev);
 }
 
 int rt_set_workgroups(rt_context* c, int32_t n_workgroups) {

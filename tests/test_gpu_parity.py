@@ -329,3 +329,67 @@ def test_quantize_device_is_the_ppm_conversion(renderer):
     assert np.array_equal(u8.cpu().numpy(), (255.999 * host).astype(np.int32).astype(np.uint8))
     orgb, _, _, _ = oracle_lib.render(sf.desc, sf.camera, sf.params, want_hit=False)
     assert np.abs(host.reshape(200, 300, 3) - orgb).max() <= TIGHT_ABS
+
+
+def test_workgroup_cap_and_frames_in_flight(renderer):
+    """rt_set_workgroups: the frame does not depend on the grid size, and several contexts rendering at
+    once on their own streams (bench.py's frames in flight) each produce the one-context frame."""
+    import torch
+    sf = scene_util.load("clutter_500", 300, 200)
+    desc = sf.desc; desc.use_bvh = 1
+    renderer.upload(desc); renderer.set_camera(sf.camera); renderer.set_params(sf.params)
+    ref, ref_hit = renderer.render()
+    rays = renderer.stats().rays
+    ctxs, streams, outs = [], [], []
+    try:
+        for wg in (1, 7, 40):
+            r = rt.Renderer(0)
+            r.upload(desc); r.set_camera(sf.camera); r.set_params(sf.params)
+            r.set_workgroups(wg)
+            ctxs.append(r)
+            streams.append(torch.cuda.Stream())
+            outs.append((torch.zeros(200 * 300 * 3, dtype=torch.float64, device="cuda"),
+                         torch.full((200 * 300,), -2, dtype=torch.int32, device="cuda")))
+        for _ in range(3):  # the first round sizes each context's node store, the others overlap
+            for r, s, (rgb, hit) in zip(ctxs, streams, outs):
+                r.render_device(rgb.data_ptr(), hit.data_ptr(), stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        for r, (rgb, hit) in zip(ctxs, outs):
+            assert np.array_equal(rgb.cpu().numpy().reshape(ref.shape), ref)
+            assert np.array_equal(hit.cpu().numpy().reshape(ref_hit.shape), ref_hit)
+            assert r.stats().rays == rays
+        with pytest.raises(rt.RtError):
+            ctxs[0].set_workgroups(-1)
+    finally:
+        for r in ctxs:
+            r.close()
+
+
+@pytest.mark.parametrize("which", ["renderer", "renderer_block", "renderer_grid", "renderer_levels", "renderer_mega"])
+def test_fused_ppm_bytes_equal_the_separate_conversion(request, which):
+    """rt_render_device_u8 == rt_render_device + rt_quantize_device, with and without the fp64 frame."""
+    import torch
+    r = request.getfixturevalue(which)
+    for name in ("clutter_500", "binary_primitives"):
+        sf = scene_util.load(name, 301, 203)
+        r.load(sf, sf.params)
+        ref, ref_hit = r.render()
+        n = ref.size
+        expect = (255.999 * ref).astype(np.int32).astype(np.uint8).reshape(-1)
+        u8 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        rgb = torch.zeros(n, dtype=torch.float64, device="cuda")
+        hit = torch.full((n // 3,), -2, dtype=torch.int32, device="cuda")
+        r.render_device_u8(u8.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        assert np.array_equal(u8.cpu().numpy(), expect)
+        u8.zero_()
+        r.render_device_u8(u8.data_ptr(), rgb.data_ptr(), hit.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(u8.cpu().numpy(), expect)
+        assert np.array_equal(rgb.cpu().numpy().reshape(ref.shape), ref)
+        assert np.array_equal(hit.cpu().numpy().reshape(ref_hit.shape), ref_hit)
+    sf = scene_util.load("pathtrace", 32, 24)
+    P = sf.params; P.mode = rt.RT_MODE_PATHTRACE
+    r.load(sf, P)
+    with pytest.raises(rt.RtError):
+        r.render_device_u8(u8.data_ptr(), None, None)
