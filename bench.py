@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="Whitted: frames in flight, one render context + stream each (default 4)")
     ap.add_argument("--workgroups", type=int, default=-1,
-                    help="workgroups per context (default: 0 = fill the chip when 1 frame is in flight, else 128 / 64)")
+                    help="workgroups per context (default: 0 = fill the chip when 1 frame is in flight, else 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,7 +117,7 @@ def main():
             streams = rtd.concurrent_streams(F, dev)  # streams that do not share a hardware queue (measured)
         except RuntimeError:
             F -= 1
-    G = args.workgroups if args.workgroups >= 0 else (0 if F == 1 else (128 if world <= 2 else 64))
+    G = args.workgroups if args.workgroups >= 0 else (0 if F == 1 else 64)
     rs = []
     for _ in range(F):
         r = rt.Renderer(local_rank)

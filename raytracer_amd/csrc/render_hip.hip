@@ -161,7 +161,9 @@ struct Tally {
 // Adds a wave's tallies to the row this wave owns (rows are per (block, wave); kernels on one
 // stream run one after another, so a plain read-modify-write is enough).  4096 waves doing 5
 // atomics each on the same 5 words cost ~250 us per launch; this costs nothing.
-RT_DEV void flush_tally(const Tally& tally, unsigned long long* counters) {
+// `overwrite`: the first kernel of a frame stores instead of adding, which spares the host a 2 MB memset per
+// frame (a fill kernel that has to wait for a free CU when several frames are in flight).
+RT_DEV void flush_tally(const Tally& tally, unsigned long long* counters, bool overwrite = false) {
     unsigned long long c[5] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl};
     for (int off = 32; off > 0; off >>= 1)
         for (int k = 0; k < 5; ++k) c[k] += __shfl_down(c[k], off);
@@ -169,7 +171,10 @@ RT_DEV void flush_tally(const Tally& tally, unsigned long long* counters) {
         unsigned row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (row < (unsigned)kCounterSlots) {
             unsigned long long* r = counters + (size_t)row * kCounterRow;
-            for (int k = 0; k < 5; ++k) r[k] += c[k];
+            if (overwrite)
+                for (int k = 0; k < 5; ++k) r[k] = c[k];
+            else
+                for (int k = 0; k < 5; ++k) r[k] += c[k];
         } else {
             for (int k = 0; k < 5; ++k)
                 if (c[k]) atomicAdd(&counters[k], c[k]);
@@ -1517,6 +1522,8 @@ struct rt_context {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     hipStream_t last_stream = nullptr;
+    unsigned long long self_clean_gen = 0;  // generation whose last frame left counters / hand-over counts ready for the next (blockwave_host.inc)
+    hipStream_t self_clean_stream = nullptr;
     double upload_ms = 0.0;
     int n_bvh_nodes = 0;
     int scene_in_lds = 0;

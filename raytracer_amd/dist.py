@@ -28,7 +28,10 @@ def strata_range(rank, world, n_strata):
     return (lo, hi) if hi > lo else (n_strata, n_strata)
 
 
-def concurrent_streams(n, device, candidates=16, spin_cycles=2_000_000):
+_concurrent = {}  # device -> streams already found to run side by side
+
+
+def concurrent_streams(n, device, candidates=32, spin_cycles=2_000_000):
     """n torch streams on `device` whose kernels really run side by side.
 
     HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams
@@ -37,7 +40,10 @@ def concurrent_streams(n, device, candidates=16, spin_cycles=2_000_000):
     plus the candidate take the time of one spin, not two.  Raises if fewer than n can be found."""
     if n <= 1:
         return [torch.cuda.current_stream(device)] if n == 1 else []
-    pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+    key = torch.device(device).index
+    if len(_concurrent.get(key, [])) >= n:
+        return _concurrent[key][:n]
+    pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]  # torch hands out its pool of 32 round-robin
 
     def spin_ms(streams):
         torch.cuda.synchronize(device)
@@ -62,6 +68,8 @@ def concurrent_streams(n, device, candidates=16, spin_cycles=2_000_000):
             break
         if min(spin_ms(chosen + [c]) for _ in range(2)) < 1.5 * one:
             chosen.append(c)
+    if len(chosen) > len(_concurrent.get(key, [])):
+        _concurrent[key] = chosen
     if len(chosen) < n:
         raise RuntimeError(f"only {len(chosen)} of {n} streams run concurrently on {device} (GPU_MAX_HW_QUEUES?)")
     return chosen
