@@ -11,7 +11,15 @@ P = sf.params
 if P.mode == 2: P.pixel_samples, P.light_samples = 16, 16
 r = rt.Renderer(0)
 r.upload(desc); r.set_camera(sf.camera); r.set_params(P)
+u8 = len(sys.argv) > 5 and sys.argv[5] == "u8"  # PPM bytes straight from the kernels, as bench.py renders
+if u8:
+    import torch
+    out = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
 for _ in range(n):
-    r.render(want_hit=False)
+    if u8:
+        r.render_device_u8(out.data_ptr(), None, None)
+        torch.cuda.synchronize()
+    else:
+        r.render(want_hit=False)
     st = r.stats()
 print(name, st.rays, st.kernel_ms)
