@@ -22,6 +22,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <utility>
+#include <vector>
 
 #include "rt_internal.hpp"
 
@@ -250,6 +252,40 @@ void build_filter_bvh(const rt_scene_desc* s, const FlatBVH* ref_bvh, FilterBVH&
     b.nodes.reserve((size_t)2 * n);
     b.build(0, n);
     const int nn = (int)b.nodes.size();
+    {
+        // Node order: the root first, then always the pending node with the largest surface area (the one a
+        // random ray is likeliest to visit next), children after their parent.  A scene whose image does not
+        // fit in LDS has the first part of this array staged there (render_hip.hip: StagedImg), so the prefix
+        // should be the most visited treelet; for scenes that fit, the order does not matter.
+        std::vector<std::pair<double, int>> heap;  // (area, old index), max-heap
+        std::vector<int> order_of;                 // new index -> old index
+        order_of.reserve(nn);
+        heap.emplace_back(b.nodes[0].box.area(), 0);
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end());
+            const int old = heap.back().second;
+            heap.pop_back();
+            order_of.push_back(old);
+            const BuildNode& bn = b.nodes[old];
+            if (bn.left >= 0) {
+                heap.emplace_back(b.nodes[bn.left].box.area(), bn.left);
+                std::push_heap(heap.begin(), heap.end());
+                heap.emplace_back(b.nodes[bn.right].box.area(), bn.right);
+                std::push_heap(heap.begin(), heap.end());
+            }
+        }
+        std::vector<int> new_of(nn, -1);
+        for (int i = 0; i < nn; ++i) new_of[order_of[i]] = i;
+        std::vector<BuildNode> re(nn);
+        for (int i = 0; i < nn; ++i) {
+            re[i] = b.nodes[order_of[i]];
+            if (re[i].left >= 0) {
+                re[i].left = new_of[re[i].left];
+                re[i].right = new_of[re[i].right];
+            }
+        }
+        b.nodes.swap(re);
+    }
     out.n_nodes = nn;
     out.scene_scale = S;
     out.box.resize((size_t)nn * 6);

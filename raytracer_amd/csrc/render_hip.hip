@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <vector>
 
 #include "device_math.hpp"
@@ -107,6 +108,7 @@ struct SceneView {
     int off_matidx, off_mat, mat_staged;              // int table: primitive ID -> material; DMaterial records; records inside lds_bytes
     int image_bytes;
     int lds_bytes;  // prefix of the image the frame kernels stage into LDS (everything the chosen traversal touches per ray)
+    int top_bytes;  // when that prefix does not fit: leading filter-BVH nodes (most visited first) staged instead, see StagedImg
     int n_lights;
     int regular;  // every coordinate is 0 or within [2^-300, 2^300]: shared-reciprocal division is exact
     int fbvh_ok, n_fnodes;                       // filter BVH present (fbvh_build.cpp)
@@ -376,6 +378,21 @@ RT_DEV HitT closest_hit_fast(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
     return best;
 }
 
+// Scene image of a scene too large for LDS: everything is read from the global copy (L1 / L2), except that the
+// first top_bytes of the image -- the leading, most visited filter-BVH nodes (fbvh_build.cpp orders them by
+// surface area) -- also sit in LDS.  Behaves like the plain pointer for `img + offset`; only the node fetch of
+// closest_hit_fbvh asks where a node lives.
+struct StagedImg {
+    const unsigned char* base;  // global copy of the whole image
+    const unsigned char* top;   // LDS copy of its first top_bytes
+    int top_bytes;
+    RT_DEV const unsigned char* operator+(long long off) const { return base + off; }
+};
+RT_DEV const unsigned char* fnode_ptr(const unsigned char* img, int off) { return img + off; }
+RT_DEV const unsigned char* fnode_ptr(const StagedImg& img, int off) { return (off < img.top_bytes ? img.top : img.base) + off; }
+RT_DEV const unsigned char* global_image(const unsigned char* img) { return img; }
+RT_DEV const unsigned char* global_image(const StagedImg& img) { return img.base; }
+
 // ---- filter-BVH traversal (fbvh_build.cpp explains why this returns the reference's answer) ------
 // Inner loop: fp32 conservative slab test on an enlarged box, children in near-to-far order for the
 // ray's octant through precomputed links (no stack), culled against the best t so far.  Leaves: the
@@ -427,7 +444,7 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
     for (;;) {
         int after = -1;  // where the walk goes on after a leaf: the leaf's "fail" link
         while (cur >= 0) {
-            const unsigned char* np = img + cur;
+            const unsigned char* np = fnode_ptr(img, cur);
             const float4 b0 = *(const float4*)np;              // lo.x hi.x lo.y hi.y
             const float2 b1 = *(const float2*)(np + 16);       // lo.z hi.z
             const int2 lk = *(const int2*)(np + link_off);
@@ -520,7 +537,7 @@ template <typename P>
 RT_DEV const DMaterial& material_of(P img, const SceneView& sv, int ref) {
     const int mi = ((const int*)(img + sv.off_matidx))[gid_of_ref(img, sv, ref)];
     // the records themselves are in the staged part only when they fit next to the geometry
-    const unsigned char* base = sv.mat_staged ? (const unsigned char*)img : sv.image;
+    const unsigned char* base = sv.mat_staged ? img + 0 : sv.image;
     return *(const DMaterial*)(base + sv.off_mat + mi * (int)sizeof(DMaterial));
 }
 
@@ -1887,6 +1904,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
                      s->n_prims, fb.n_nodes, fb.n_nodes * kFNodeBytes, s->n_prims * kLeafBytes, sv.off_gid_sph - sv.off_sph, mat_bytes,
                      sv.mat_staged ? "staged" : "global", sv.lds_bytes, sv.image_bytes);
     if (!(fb.ok && c->traversal == 3 && c->wavefront)) sv.lds_bytes = sv.image_bytes;  // the per-pixel kernel walks the reference tree
+    // too large for LDS: the leading filter nodes are staged instead (the launch trims this to the kernel's room)
+    sv.top_bytes = (fb.ok && c->traversal == 3 && c->wavefront && sv.lds_bytes > kMaxLdsImage && sv.off_fnodes == 0)
+                       ? (int)std::min<long long>((long long)fb.n_nodes * kFNodeBytes, 160 * 1024) : 0;
+    if (const char* e = std::getenv("RT_STAGE_TOP")) if (std::atoi(e) == 0) sv.top_bytes = 0;  // A/B: everything from the global copy
     // Culling margin per node (closest_hit_fast<kCull>): absolute slack of 1e-6 of the box's size and
     // position, or +inf when some primitive below the node is not contained in its reference box
     // (cylinders whose axis is not exactly +Y, src/Cylinder.cpp:131-137): such nodes are never culled.

@@ -21,3 +21,21 @@ for n_sph, n_tri, n_cyl in [(300, 60, 20), (1500, 300, 100), (15000, 3000, 1000)
     st = r.stats()
     print(f"soup {len(types):6d} prims 1920x1080 lds={st.scene_in_lds} rays={st.rays} {np.median(ms):.3f} ms  "
           f"{st.rays/np.median(ms)/1e3:.0f} Mrays/s", flush=True)
+
+# generated clutter scenes (scripts/gen_clutter.py), 4K
+import importlib.util, json, tempfile
+spec = importlib.util.spec_from_file_location("gen_clutter", os.path.join(ROOT, "scripts", "gen_clutter.py"))
+gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+for n in (500, 5000, 50000, 500000):
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(gen.clutter(n, seed=1, width=3840, height=2160), f)
+    sf = rt.SceneFile(f.name)
+    os.unlink(f.name)
+    r.upload(sf.desc); r.set_camera(sf.camera); r.set_params(sf.params)
+    r.render(want_hit=False)
+    ms = []
+    for _ in range(3):
+        r.render(want_hit=False); ms.append(r.stats().kernel_ms)
+    st = r.stats()
+    print(f"clutter {n:7d} spheres 3840x2160 lds={st.scene_in_lds} upload={st.upload_ms:.0f} ms rays={st.rays} {np.median(ms):.3f} ms  "
+          f"{st.rays/np.median(ms)/1e3:.0f} Mrays/s", flush=True)

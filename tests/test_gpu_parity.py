@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 
 import raytracer_amd as rt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from tests import oracle_lib, scene_util
 
 pytestmark = pytest.mark.gpu
@@ -393,3 +395,23 @@ def test_fused_ppm_bytes_equal_the_separate_conversion(request, which):
     r.load(sf, P)
     with pytest.raises(rt.RtError):
         r.render_device_u8(u8.data_ptr(), None, None)
+
+
+@pytest.mark.parametrize("n_spheres,bvh", [(5000, True), (5000, False), (60000, True)])
+def test_generated_clutter_scenes(renderer, tmp_path, n_spheres, bvh):
+    """seeded large clutter scenes (scripts/gen_clutter.py) -- the filter BVH's top is staged in
+    LDS, the rest of the image is read from HBM; both tie rules."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("gen_clutter", os.path.join(ROOT, "scripts", "gen_clutter.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    path = tmp_path / "clutter.json"
+    path.write_text(json.dumps(gen.clutter(n_spheres, seed=3, width=192, height=128, bvh=bvh)))
+    sf = rt.SceneFile(str(path))
+    renderer.load(sf, sf.params)
+    rgb, hit = renderer.render()
+    st = renderer.stats()
+    assert st.scene_in_lds == 0
+    orgb, ohit, cnt, _ = oracle_lib.render(sf.desc, sf.camera, sf.params)
+    assert_frame_parity(rgb, hit, st, orgb, ohit, cnt)
