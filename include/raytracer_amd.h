@@ -192,6 +192,9 @@ int rt_camera_look_at(rt_camera* out, const double position[3], const double loo
 
 /* RayTracer::writeImageToPPM (RayTracer.cpp:352-367): byte-identical ASCII P3. */
 int rt_write_ppm(const char* path, const double* rgb, int32_t width, int32_t height);
+/* The same file from the PPM payload bytes of rt_render_u8 / rt_render_device_u8 (already
+ * int(255.999 * c), RayTracer.cpp:359-362): byte-identical to rt_write_ppm on the fp64 frame. */
+int rt_write_ppm_u8(const char* path, const uint8_t* rgb8, int32_t width, int32_t height);
 
 /* BVHNode::BVHNode (src/BVHNode.cpp:7-45) flattened: returns the number of nodes and, when the
  * out pointers are non-NULL, fills caller arrays of capacity `cap` nodes.  child refs >= 0 are
@@ -233,6 +236,12 @@ int rt_pathtrace_accumulate_device(rt_context* ctx, void* stream, double* accum_
  * eighth of the fp64 frame, which is what a multi-GPU job moves over xGMI to the rank that writes
  * the file. */
 int rt_quantize_device(rt_context* ctx, void* stream, const double* rgb_dev, int64_t n_values, uint8_t* out_dev);
+
+/* rt_render for callers that only want the image file's payload (the CLI): the frame as
+ * int(255.999 * c) bytes in a host buffer of 3*W*local_rows bytes -- an eighth of rt_render's
+ * device-to-host copy.  Whitted / binary: written by the kernels' pixel store; path trace:
+ * accumulate, resolve (RayTracer.cpp:301-315) and convert on the device. */
+int rt_render_u8(rt_context* ctx, uint8_t* rgb8, int32_t* hit_id);
 
 /* rt_render_device with the PPM conversion fused into the kernels' pixel store (binary / phong modes):
  * rgb8_dev receives int(255.999 * c) per component (RayTracer.cpp:359-362 applied to the clamped

@@ -98,6 +98,14 @@ class Renderer:
         capi.check(self._lib.rt_render(self._h, rgb.ctypes.data, hit.ctypes.data if want_hit else None), "rt_render")
         return rgb, hit
 
+    def render_u8(self, want_hit=False):
+        """Blocking render of the PPM payload: (uint8 [rows, W, 3] = int(255.999 * c), hit_id or None)."""
+        rows, W = self.local_rows, self.params.width
+        u8 = np.empty((rows, W, 3), dtype=np.uint8)
+        hit = np.empty((rows, W), dtype=np.int32) if want_hit else None
+        capi.check(self._lib.rt_render_u8(self._h, u8.ctypes.data, hit.ctypes.data if want_hit else None), "rt_render_u8")
+        return u8, hit
+
     def render_device(self, rgb_ptr, hit_ptr=None, stream=None):
         capi.check(self._lib.rt_render_device(self._h, stream, rgb_ptr, hit_ptr), "rt_render_device")
 
@@ -163,3 +171,10 @@ def write_ppm(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float64)
     H, W = rgb.shape[0], rgb.shape[1]
     capi.check(capi.load().rt_write_ppm(str(path).encode(), rgb.ctypes.data, W, H), "rt_write_ppm")
+
+
+def write_ppm_u8(path, rgb8):
+    """The same file from PPM payload bytes (Renderer.render_u8)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    H, W = rgb8.shape[0], rgb8.shape[1]
+    capi.check(capi.load().rt_write_ppm_u8(str(path).encode(), rgb8.ctypes.data, W, H), "rt_write_ppm_u8")

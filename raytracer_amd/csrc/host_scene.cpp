@@ -525,23 +525,26 @@ int rt_build_bvh(const rt_scene_desc* scene, int32_t cap, double* node_box, int3
     return n;
 }
 
-int rt_write_ppm(const char* path, const double* rgb, int32_t width, int32_t height) {
-    if (!path || !rgb || width <= 0 || height <= 0) return rt::set_error(RT_ERR_INVALID, "rt_write_ppm: bad argument");
+}  // extern "C"
+
+namespace {
+// P3 body shared by the two writers: "r g b\n" per pixel, rows from j = H-1 down (RayTracer.cpp:352-367).  A
+// table of the decimal strings keeps the 4K case (25 M numbers) quick.  value(row, k) -> the integer to print.
+template <typename Row, typename Value>
+int write_p3(const char* path, const Row* data, int32_t width, int32_t height, Value value) {
     FILE* fp = std::fopen(path, "wb");
     if (!fp) return rt::set_error(RT_ERR_IO, "could not open %s for writing", path);
     std::fprintf(fp, "P3\n%d %d\n255\n", width, height);
-    // "r g b\n" per pixel, rows from j = H-1 down; int(255.999 * c) as in RayTracer.cpp:359-362.
-    // A table of the decimal strings keeps the 4K case (25 M numbers) quick.
     char digits[256][4];
     int dlen[256];
     for (int v = 0; v < 256; ++v) dlen[v] = std::snprintf(digits[v], 4, "%d", v);
     std::vector<char> line((size_t)width * 12 + 16);
     for (int j = height - 1; j >= 0; --j) {
         char* p = line.data();
-        const double* row = rgb + (size_t)j * width * 3;
+        const Row* row = data + (size_t)j * width * 3;
         for (int i = 0; i < width; ++i) {
             for (int c = 0; c < 3; ++c) {
-                int v = static_cast<int>(255.999 * row[i * 3 + c]);
+                int v = value(row[i * 3 + c]);
                 if (v >= 0 && v < 256) {
                     std::memcpy(p, digits[v], (size_t)dlen[v]);
                     p += dlen[v];
@@ -559,6 +562,20 @@ int rt_write_ppm(const char* path, const double* rgb, int32_t width, int32_t hei
     }
     if (std::fclose(fp) != 0) return rt::set_error(RT_ERR_IO, "write to %s failed", path);
     return RT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_write_ppm(const char* path, const double* rgb, int32_t width, int32_t height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return rt::set_error(RT_ERR_INVALID, "rt_write_ppm: bad argument");
+    // int(255.999 * c) as in RayTracer.cpp:359-362
+    return write_p3(path, rgb, width, height, [](double c) { return static_cast<int>(255.999 * c); });
+}
+
+int rt_write_ppm_u8(const char* path, const uint8_t* rgb8, int32_t width, int32_t height) {
+    if (!path || !rgb8 || width <= 0 || height <= 0) return rt::set_error(RT_ERR_INVALID, "rt_write_ppm_u8: bad argument");
+    return write_p3(path, rgb8, width, height, [](uint8_t v) { return (int)v; });
 }
 
 }  // extern "C"

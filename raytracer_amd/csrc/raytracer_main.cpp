@@ -6,6 +6,7 @@
 // invocation): RT_DEVICE (GPU ordinal), RT_WIDTH / RT_HEIGHT (override camera.width/height; the
 // aspect ratio of the camera follows, as it would after editing the JSON), RT_SEED.
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,15 +73,16 @@ int main(int argc, char* argv[]) {
         std::cout << "Light samples: " << params.light_samples << std::endl;
     }
 
-    std::vector<double> rgb((size_t)params.width * params.height * 3);
-    if (rt_render(ctx, rgb.data(), nullptr) != RT_OK) {
+    // the file's payload straight from the device: int(255.999 * c) bytes (RayTracer.cpp:359-362)
+    std::vector<uint8_t> rgb((size_t)params.width * params.height * 3);
+    if (rt_render_u8(ctx, rgb.data(), nullptr) != RT_OK) {
         std::cerr << "Error: " << rt_last_error() << std::endl;
         return 1;
     }
     std::cout << "\rRendering: 100% completed" << std::flush;
     rt_stats st;
     rt_get_stats(ctx, &st);
-    if (rt_write_ppm(out_path.c_str(), rgb.data(), params.width, params.height) != RT_OK) {
+    if (rt_write_ppm_u8(out_path.c_str(), rgb.data(), params.width, params.height) != RT_OK) {
         std::cerr << "Error: " << rt_last_error() << std::endl;
         return 1;
     }

@@ -2136,6 +2136,41 @@ int rt_quantize_device(rt_context* c, void* stream, const double* rgb_dev, int64
     return RT_OK;
 }
 
+int rt_render_u8(rt_context* c, uint8_t* rgb8, int32_t* hit_id) {
+    if (!c || !rgb8) return rt::set_error(RT_ERR_INVALID, "rt_render_u8: null argument");
+    if (!c->have_params) return rt::set_error(RT_ERR_STATE, "rt_render_u8: params not set");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n_px = (size_t)local_rows_of(c->params) * c->params.width;
+    const bool pt = c->params.mode == RT_MODE_PATHTRACE;
+    unsigned char* d_u8 = nullptr;
+    double* d_rgb = nullptr;  // path trace: the sums, then the resolved frame
+    int* d_hit = nullptr;
+    auto release = [&]() {
+        (void)hipFree(d_u8);
+        (void)hipFree(d_rgb);
+        (void)hipFree(d_hit);
+    };
+    hipError_t e = hipMalloc((void**)&d_u8, std::max<size_t>(n_px, 1) * 3);
+    if (e == hipSuccess && pt) e = hipMalloc((void**)&d_rgb, std::max<size_t>(n_px, 1) * 3 * sizeof(double));
+    if (e == hipSuccess && hit_id) {
+        e = hipMalloc((void**)&d_hit, std::max<size_t>(n_px, 1) * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(d_hit, 0xFF, std::max<size_t>(n_px, 1) * sizeof(int));
+    }
+    if (e != hipSuccess) {
+        release();
+        return rt::set_error(RT_ERR_DEVICE, "rt_render_u8: hipMalloc -> %s", hipGetErrorString(e));
+    }
+    int rc = pt ? launch_render(c, nullptr, d_rgb, d_hit, false) : launch_render(c, nullptr, nullptr, d_hit, false, d_u8);
+    if (rc == RT_OK && pt) rc = rt_quantize_device(c, nullptr, d_rgb, (int64_t)n_px * 3, d_u8);
+    if (rc == RT_OK) {
+        e = hipMemcpy(rgb8, d_u8, n_px * 3, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && hit_id) e = hipMemcpy(hit_id, d_hit, n_px * sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = rt::set_error(RT_ERR_DEVICE, "rt_render_u8: kernel or copy failed -> %s", hipGetErrorString(e));
+    }
+    release();
+    return rc;
+}
+
 int rt_render(rt_context* c, double* rgb, int32_t* hit_id) {
     if (!c || !rgb) return rt::set_error(RT_ERR_INVALID, "rt_render: null argument");
     if (!c->have_params) return rt::set_error(RT_ERR_STATE, "rt_render: params not set");

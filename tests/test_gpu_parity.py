@@ -415,3 +415,34 @@ def test_generated_clutter_scenes(renderer, tmp_path, n_spheres, bvh):
     assert st.scene_in_lds == 0
     orgb, ohit, cnt, _ = oracle_lib.render(sf.desc, sf.camera, sf.params)
     assert_frame_parity(rgb, hit, st, orgb, ohit, cnt)
+
+
+@pytest.mark.parametrize("name,tonemap", [("binary_primitives", None), ("mirror_glass_cylinder", None), ("clutter_500", None)])
+def test_cli_writes_the_reference_file(name, tonemap, ref_outputs, tmp_path):
+    """The drop-in binary, invoked as the reference is (`raytracer scene.json out.ppm`): its file has the
+    reference's sha256; it renders PPM bytes on the device (rt_render_u8 / rt_write_ppm_u8)."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "csrc", "raytracer")
+    out = tmp_path / "o.ppm"
+    res = subprocess.run([exe, os.path.join("scenes", name + ".json"), str(out)] + ([tonemap] if tonemap else []),
+                         cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "Rendering complete. Image saved to" in res.stdout
+    assert hashlib.sha256(out.read_bytes()).hexdigest() == ref_outputs[name]["sha256"]
+
+
+def test_render_u8_is_the_quantized_frame(renderer, tmp_path):
+    """rt_render_u8 / rt_write_ppm_u8 == rt_render + rt_write_ppm, Whitted and path-traced."""
+    for name, mode in (("clutter_500", None), ("pathtrace", rt.RT_MODE_PATHTRACE)):
+        sf = scene_util.load(name, 150, 100)
+        P = sf.params
+        if mode is not None:
+            P.mode, P.pixel_samples, P.light_samples = mode, 4, 2
+        renderer.load(sf, P)
+        rgb, hit = renderer.render()
+        u8, hit8 = renderer.render_u8(want_hit=True)
+        assert np.array_equal(u8, (255.999 * rgb).astype(np.int32).astype(np.uint8))
+        assert np.array_equal(hit8, hit)
+        a, b = tmp_path / "a.ppm", tmp_path / "b.ppm"
+        rt.write_ppm(a, rgb); rt.write_ppm_u8(b, u8)
+        assert a.read_bytes() == b.read_bytes()
