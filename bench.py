@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--workgroups", type=int, default=-1,
                     help="workgroups per context (default: 0 = fill the chip when 1 frame is in flight, else 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="rehearsal on one GPU: render rank 0's share of an N-rank job (no collective); the printed "
+                         "value then refers to that share only")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,7 +98,7 @@ def main():
     if pathtrace:
         P.sample_begin, P.sample_end = rtd.strata_range(rank, world, base.pixel_samples)
     else:
-        P.band_rank, P.band_world = rank, world
+        P.band_rank, P.band_world = (0, args.emulate_world) if (args.emulate_world > 0 and world == 1) else (rank, world)
     rw.upload(desc)
     rw.set_camera(sf.camera)
     rw.set_params(P)
