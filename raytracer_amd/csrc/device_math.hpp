@@ -27,8 +27,22 @@ RT_DEV D3 operator-(D3 a) { return D3{-a.x, -a.y, -a.z}; }
 RT_DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // Vector3.cpp:48-50
 RT_DEV D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 RT_DEV double length(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // Vector3.cpp:72-75
-RT_DEV D3 normalize(D3 a) {                                                       // Vector3.cpp:78-81
-    double len = length(a);
+RT_DEV double refine_rcp(double d);
+RT_DEV double div_shared(double a, double d, double r);
+// Vector3.cpp:78-81: three true divisions by the same length.  hipcc expands each into 11-12 instructions; when
+// no quotient needs v_div_scale's scaling -- every component in [2^-400, inf) in magnitude and the length at most
+// 2^400, so that quotients lie in [2^-800, 1] -- the same bits come from one refined reciprocal and 3
+// instructions per component (see refine_rcp / div_shared below).  Zero, tiny, huge or non-finite components
+// take the literal divisions.  tests/test_gpu_rays.py::test_normalize_shares_one_reciprocal_exactly.
+RT_DEV D3 normalize(D3 a) {
+    const double len = length(a);
+    const unsigned hx = (unsigned)__double2hiint(a.x) & 0x7FFFFFFFu, hy = (unsigned)__double2hiint(a.y) & 0x7FFFFFFFu,
+                   hz = (unsigned)__double2hiint(a.z) & 0x7FFFFFFFu;
+    const unsigned smallest = min(min(hx, hy), hz);
+    if (smallest >= 0x26F00000u && (unsigned)__double2hiint(len) <= 0x58F00000u) {  // 2^-400, 2^400
+        const double r = refine_rcp(len);
+        return D3{div_shared(a.x, len, r), div_shared(a.y, len, r), div_shared(a.z, len, r)};
+    }
     return D3{a.x / len, a.y / len, a.z / len};
 }
 RT_DEV D3 ld3(const double* p) { return D3{p[0], p[1], p[2]}; }

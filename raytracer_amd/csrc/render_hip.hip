@@ -1501,6 +1501,8 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
             break;
         }
         case 8: r = div_shared(x, y, refine_rcp(y)); break;  // exact division through a shared reciprocal
+        case 9: r = normalize(mk(x, y, 0.75 * y)).x; break;  // Vector3::normalize (shared reciprocal when it is exact)
+        case 10: r = normalize(mk(y, 0.75 * y, x)).z; break;
         default: r = 0.0;
     }
     out[k] = r;

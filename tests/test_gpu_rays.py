@@ -52,6 +52,35 @@ def test_shared_reciprocal_division_is_exact(renderer):
     assert np.array_equal(got, a / d)
 
 
+def test_normalize_shares_one_reciprocal_exactly(renderer):
+    """device_math.hpp normalize: one refined reciprocal of the length when no quotient can need v_div_scale's
+    scaling, the literal divisions otherwise -- either way the bits of Vector3::normalize (x / sqrt(x*x + y*y + z*z))."""
+    rng = np.random.default_rng(17)
+    n = 4_000_000
+    x = rng.standard_normal(n) * np.exp2(rng.uniform(-30, 30, n))
+    y = rng.standard_normal(n) * np.exp2(rng.uniform(-30, 30, n))
+    # around the guard's limits, far outside them, zeros, adversarial mantissas
+    k = 400_000
+    x[:k] = rng.standard_normal(k) * np.exp2(rng.uniform(-450, 450, k))
+    y[:k] = rng.standard_normal(k) * np.exp2(rng.uniform(-450, 450, k))
+    x[k:k + 1000] = 0.0
+    y[k + 500:k + 1500] = 0.0
+    x[2 * k:3 * k] = np.frombuffer((np.uint64(0x3FEFFFFFFFFFFFFF) - rng.integers(0, 4, k).astype(np.uint64)).tobytes(), dtype=np.float64)
+    y[3 * k:4 * k] = np.frombuffer((np.uint64(0x3FF0000000000000) + rng.integers(0, 4, k).astype(np.uint64)).tobytes(), dtype=np.float64)
+    x[-4:] = [np.inf, 1e-320, 1e300, -0.0]
+    y[-4:] = [1.0, 1e-320, 1e300, 1.0]
+    z = 0.75 * y
+    with np.errstate(all="ignore"):
+        ex = x / np.sqrt(x * x + y * y + z * z)
+        ez = x / np.sqrt(y * y + z * z + x * x)
+    got = renderer.math(9, x, y)
+    assert np.array_equal(got, ex, equal_nan=True)
+    assert np.array_equal(np.signbit(got), np.signbit(ex))
+    got = renderer.math(10, x, y)
+    assert np.array_equal(got, ez, equal_nan=True)
+    assert np.array_equal(np.signbit(got), np.signbit(ez))
+
+
 def test_transcendentals_within_a_few_ulp(renderer):
     """pow/atan2/acos/cos/sin of the device library are not bit-identical to glibc; the contract only
     needs colours within 1e-4.  Measured: <= 2 ulp."""
