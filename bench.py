@@ -118,7 +118,7 @@ def main():
     while F > 1 and streams is None:
         try:
             streams = rtd.concurrent_streams(F, dev)  # streams that do not share a hardware queue (measured)
-        except RuntimeError:
+        except Exception:  # fewer streams overlap than asked for (or the probe is unavailable): fewer frames in flight
             F -= 1
     G = args.workgroups if args.workgroups >= 0 else (0 if F == 1 else 64)
     rs = []
