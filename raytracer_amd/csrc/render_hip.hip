@@ -36,6 +36,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "device_math.hpp"
@@ -1522,6 +1524,7 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
 struct rt_context {
     int device = 0;
     int n_cus = 0;
+    std::map<std::tuple<const void*, int, size_t>, int> grid_cache;  // wf_persistent_grid: workgroups per CU
     int max_workgroups = 0;  // cap on a persistent kernel's grid (0: as many as the chip holds), RT_WORKGROUPS / rt_set_workgroups
     bool have_scene = false, have_camera = false, have_params = false;
     SceneView sv;
