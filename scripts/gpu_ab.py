@@ -3,7 +3,6 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
-from tests import oracle_lib
 
 def bench(r, sf, desc, P, n=5):
     r.upload(desc); r.set_camera(sf.camera); r.set_params(P)
