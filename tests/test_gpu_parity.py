@@ -446,3 +446,52 @@ def test_render_u8_is_the_quantized_frame(renderer, tmp_path):
         a, b = tmp_path / "a.ppm", tmp_path / "b.ppm"
         rt.write_ppm(a, rgb); rt.write_ppm_u8(b, u8)
         assert a.read_bytes() == b.read_bytes()
+
+
+def test_frame_pipeline_with_frames_in_flight_on_streams(renderer):
+    """bench.py's loop at world size 1: 4 contexts of 16 workgroups on 4 streams that were measured to overlap
+    (dist.concurrent_streams), PPM bytes from the kernels, 10 frames dealt round-robin through FramePipeline."""
+    import torch
+    from raytracer_amd import dist as rtd
+    sf = scene_util.load("mirror_glass_cylinder", 304, 200)
+    renderer.load(sf, sf.params)
+    ref, _ = renderer.render()
+    expect = (255.999 * ref).astype(np.int32).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    try:
+        streams = rtd.concurrent_streams(4, dev)
+        assert rtd.concurrent_streams(2, dev) == streams[:2]  # cached
+    except RuntimeError:  # fewer hardware queues than on the MI355X boxes: overlap is a matter of speed only
+        streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
+    ctxs = []
+    try:
+        for _ in range(4):
+            r = rt.Renderer(0)
+            r.load(sf, sf.params)
+            r.set_workgroups(16)
+            ctxs.append(r)
+        H, W = sf.params.height, sf.params.width
+        pipe = rtd.FramePipeline(0, 1, H, W, dev, band_rows=sf.params.band_rows, depth=4, streams=streams)
+        frames = []
+        n = 10
+        def finish(k):
+            with torch.cuda.stream(pipe.stream(k)):
+                frames.append(pipe.complete(k).clone())
+        for k in range(n):
+            with torch.cuda.stream(pipe.stream(k)):
+                _, u8 = pipe.target(k)
+                u8.zero_()
+                ctxs[k % 4].render_device_u8(u8.data_ptr(), None, None, stream=torch.cuda.current_stream().cuda_stream)
+                pipe.submit(k)
+            if k >= 3:
+                finish(k - 3)
+        for k in range(n - 3, n):
+            finish(k)
+        torch.cuda.synchronize()
+        assert len(frames) == n
+        for f in frames:
+            assert np.array_equal(f.cpu().numpy(), expect)
+    finally:
+        for r in ctxs:
+            r.close()
