@@ -240,7 +240,7 @@ def main():
         }
         # HBM bytes per frame from the PMC passes (collected offline with rocprofv3 --pmc, see the file): not
         # measurable inside this process, so it is quoted from the committed profile of the same workload
-        tpath = os.path.join(ROOT, "profiles", "r01_h_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
         if not pathtrace and world == 1 and os.path.exists(tpath):
             tr = json.load(open(tpath))
             line["roofline"]["traffic"] = tr["fetch_bytes_raw"] + tr["write_bytes"]
