@@ -230,6 +230,10 @@ def main():
                          "kernel": ("bw_kernel + bw_accumulate_path_kernel per batch of strata (per depth: trace, shadow, shade; combine)" if pathtrace
                                     else "fw_roots_kernel (level 0) + fw_kernel (depth >= 1: fused trace/shadow/shade per level, combine, tone map)"),
                          "kernel_ms": k_ms, "launches_in_flight": F, "workgroups_per_launch": G or "all",
+                         # one launch's own rate (ops of one launch / its duration): with F launches in flight it
+                         # runs on 1/F of the chip, so `achieved` above is the ops of all launches over the timed
+                         # region instead; with --in-flight 1 the two definitions coincide
+                         "achieved_per_launch": alg_ops / world / (k_ms * 1e-3) / 1e12,
                          "ops_per_ray": alg_ops / max(rays, 1.0),
                          "reference_box_tests_per_ray": boxes / max(rays, 1.0),
                          # counters of the production traversal are compiled out (-DRT_FBVH_COUNTS=1 turns them on;
