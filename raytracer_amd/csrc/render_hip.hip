@@ -1453,6 +1453,7 @@ __global__ void __launch_bounds__(256) quantize_kernel(const double* rgb, long l
 #include "wavefront_kernels.inc"
 #include "blockwave_kernels.inc"
 #include "fused_kernels.inc"
+#include "pathwave_kernels.inc"
 #include "gridwave_kernels.inc"
 
 // ---- diagnostics kernels (rt_debug_*) ------------------------------------------------------------
@@ -1554,6 +1555,7 @@ struct rt_context {
     int traversal = 3;           // 0 ref, 1 walk (same visits as the reference), 2 cull (+ any-hit shadows), 3 filter BVH
     bool wavefront = true;       // RT_PIPELINE=mega selects the persistent per-pixel kernel
     bool level_kernels = false;  // RT_PIPELINE=levels: one kernel per phase and depth instead of one per frame
+    bool pt_generic = false;     // RT_PT_GENERIC=1: path trace with bw_kernel<1> (any lights / sample counts) even where pt_kernel applies
     int fused = -1;              // one pass per level (fused_kernels.inc): -1 = Whitted yes, path trace no; RT_PIPELINE=fused / block force it
     unsigned* d_bw_info = nullptr;
     uint2* d_gw_lvl = nullptr;       // gridwave: per level, per workgroup (first id, count)
@@ -1765,6 +1767,7 @@ int rt_create(rt_context** out, int device) {
     c->fused = pipe && std::strcmp(pipe, "fused") == 0 ? 1 : (pipe && std::strcmp(pipe, "block") == 0 ? 0 : -1);
     c->gridwave = pipe && std::strcmp(pipe, "grid") == 0;
     if (const char* e = std::getenv("RT_SPLIT_ROOTS")) c->split_roots = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_PT_GENERIC")) c->pt_generic = std::atoi(e) != 0;
     c->n_cus = prop.multiProcessorCount;
     if (const char* e = std::getenv("RT_WORKGROUPS")) c->max_workgroups = std::max(0, std::atoi(e));
     std::memset(&c->sv, 0, sizeof c->sv);
