@@ -54,4 +54,12 @@ void prim_bounds(const rt_scene_desc* scene, int prim, double box[6]);
 // Triangle::Triangle normal (src/Triangle.cpp:7-12).
 void triangle_normal(const double* v0, const double* v1, const double* v2, double n[3]);
 
+// Host-side handles of the frame kernels, one translation unit per family (k_blockwave.hip, k_fused.hip,
+// k_pathwave.hip); every one has the signature (SceneView, RenderArgs, BwArgs) and is launched through
+// hipLaunchKernel.  tv = traversal - 1 (0 walk, 1 cull, 2 filter BVH).
+const void* bw_kernel_ptr(bool path_trace, bool lds, int tv);
+const void* fw_kernel_ptr(bool path_trace, bool lds, int tv);
+const void* fw_roots_kernel_ptr(bool lds, int tv);
+const void* pt_kernel_ptr(bool lds, int tv);
+
 }  // namespace rt
