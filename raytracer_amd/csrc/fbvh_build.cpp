@@ -212,15 +212,19 @@ void build_filter_bvh(const rt_scene_desc* s, const FlatBVH* ref_bvh, FilterBVH&
                 bx.hi[k] = std::max({g[k], g[3 + k], g[6 + k]});
             }
         } else {
-            // true extent of a capped cylinder, bounded by the sphere around its mid-point
+            // true extent of the capped cylinder the reference intersects (base .. base + axis * h, radius r;
+            // src/Cylinder.cpp:13-107 -- not the +Y box of its getBoundingBox): along coordinate k the two cap
+            // discs reach |a_k| h / 2 + r sqrt(1 - a_k^2) from the mid-point.  A bounding-sphere box, as used before,
+            // is 5.6 times the volume for pathtrace.json's upright cylinder, and the cylinder test is the most
+            // expensive one there is (150 flops, 4 divisions, a square root).
             double len = std::sqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5]);
             double ax[3] = {g[3] / len, g[4] / len, g[5] / len};
             double h = g[7], r = std::fabs(g[6]);
-            double rad = std::sqrt(0.25 * h * h + r * r) * (1.0 + 1e-12);
             for (int k = 0; k < 3; ++k) {
                 double c = g[k] + ax[k] * h * 0.5;
-                bx.lo[k] = c - rad;
-                bx.hi[k] = c + rad;
+                double e = (std::fabs(ax[k]) * std::fabs(h) * 0.5 + r * std::sqrt(std::max(0.0, 1.0 - ax[k] * ax[k]))) * (1.0 + 1e-9) + 1e-300;
+                bx.lo[k] = c - e;
+                bx.hi[k] = c + e;
             }
         }
         for (int k = 0; k < 3; ++k) {

@@ -1,0 +1,15 @@
+#!/bin/bash
+# PMC pass over a few path-traced 1080p frames of pathtrace.json (run through gpurun from the repo root):
+#   scripts/gpu_pmc_pt.sh <tag>   -> gpurun_out/r02/pmc_<tag>.csv
+set -e -o pipefail
+TAG=${1:-x}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/r02/pmc_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 120 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d "$OUT/sq" -o pmc -- python3 "$ROOT/scripts/gpu_prof_case.py" pathtrace 1920 1080 2 > /dev/null
+timeout -s KILL 120 rocprofv3 --output-format csv --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAVES -d "$OUT/sq2" -o pmc -- python3 "$ROOT/scripts/gpu_prof_case.py" pathtrace 1920 1080 2 > /dev/null
+cd "$ROOT"
+python3 scripts/pmc_summary.py "$ROOT/gpurun_out/r02/pmc_$TAG.csv" $(find "$OUT" -name "*counter_collection.csv" | sort)
+rm -rf "$OUT"
+grep "pt_kernel\|bw_kernel" "$ROOT/gpurun_out/r02/pmc_$TAG.csv"

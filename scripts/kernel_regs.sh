@@ -1,13 +1,16 @@
 #!/bin/bash
-# VGPR / scratch / LDS usage of the kernels in libraytracer_amd.so (from the code object's metadata)
+# VGPR / scratch / LDS usage of the kernels of libraytracer_amd.so (from the code objects' metadata), one
+# translation unit at a time: scripts/kernel_regs.sh [object files...]  (default: the production objects)
 set -e
-lib=${1:-/root/repo/raytracer_amd/csrc/libraytracer_amd.so}
 L=/opt/rocm/lib/llvm/bin
-$L/llvm-objcopy --dump-section .hip_fatbin=/tmp/rt_fat.bin "$lib"
-$L/clang-offload-bundler --unbundle --type=o --input=/tmp/rt_fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=/tmp/rt_dev.o
-$L/llvm-readelf --notes /tmp/rt_dev.o | python3 -c "
+cd "$(dirname "$0")/../raytracer_amd/csrc"
+objs=${@:-render_hip.o k_blockwave.o k_fused.o k_pathwave.o}
+for o in $objs; do
+  $L/llvm-objcopy --dump-section .hip_fatbin=/tmp/rt_fat.bin "$o" /tmp/rt_unused.o
+  $L/clang-offload-bundler --unbundle --type=o --input=/tmp/rt_fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=/tmp/rt_dev.o
+  $L/llvm-readelf --notes /tmp/rt_dev.o | python3 -c "
 import sys,re
-name=None; rec={}
+rec={}
 for line in sys.stdin:
     m=re.search(r'\.(name|vgpr_count|agpr_count|sgpr_count|private_segment_fixed_size|vgpr_spill_count|group_segment_fixed_size):\s+(\S+)', line)
     if not m: continue
@@ -17,3 +20,4 @@ for line in sys.stdin:
     if len(rec['cur'])==7:
         c=rec.pop('cur'); print(c['name'][:70].ljust(70), 'vgpr',c['vgpr_count'],'agpr',c['agpr_count'],'spill',c['vgpr_spill_count'],'scratch',c['private_segment_fixed_size'],'lds',c['group_segment_fixed_size'])
 "
+done
