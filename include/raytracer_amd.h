@@ -279,7 +279,8 @@ int rt_debug_trace_rays(rt_context* ctx, int64_t n, const double* origins, const
 /* out[k] = op(a[k], b[k]) evaluated on the device: 0 a/b, 1 sqrt(a), 2 pow(a,b), 3 atan2(a,b),
  * 4 acos(a), 5 cos(a), 6 sin(a), 7 RNG uniform(seed 0; pixel a, sample b, node 1, dim 0),
  * 8 a/b through the shared-reciprocal sequence the traversal uses, 9 / 10 the x (z) component of
- * normalize((a, b, 0.75 b)) (of normalize((b, 0.75 b, a))). */
+ * normalize((a, b, 0.75 b)) (of normalize((b, 0.75 b, a))), 11 / 12 the x (z) component of (a, 0.75 a, -1.5 a) / b
+ * (of (0.75 a, -1.5 a, a) / b) through the shared-reciprocal Vector3 / double. */
 int rt_debug_math(rt_context* ctx, int op, int64_t n, const double* a, const double* b, double* out);
 
 #ifdef __cplusplus

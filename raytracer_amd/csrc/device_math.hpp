@@ -113,6 +113,21 @@ RT_DEV double div_shared(double a, double d, double r) {
     double rem = __builtin_fma(-d, q, a);
     return __builtin_fma(rem, r, q);
 }
+// a / d for three numerators over one denominator (D3 / double of the reference: AreaLight.cpp:13, RayTracer.cpp:678),
+// bit-identical to the three true divisions: when |d| and every |a_k| lie in [2^-300, 2^300] no operand or quotient
+// can need v_div_scale's scaling, and one refined reciprocal serves all three (11 + 2 x 3 instructions instead of
+// 3 x 11); zero, tiny, huge or non-finite operands take the literal divisions.
+RT_DEV D3 div3(D3 a, double d) {
+    const unsigned hx = (unsigned)__double2hiint(a.x) & 0x7FFFFFFFu, hy = (unsigned)__double2hiint(a.y) & 0x7FFFFFFFu,
+                   hz = (unsigned)__double2hiint(a.z) & 0x7FFFFFFFu, hd = (unsigned)__double2hiint(d) & 0x7FFFFFFFu;
+    const unsigned lo = min(min(hx, hy), min(hz, hd)), hi = max(max(hx, hy), max(hz, hd));
+    if (lo >= 0x2D300000u && hi <= 0x52B00000u) {  // 2^-300, 2^300
+        const double r = refine_rcp(d);
+        return D3{div_shared(a.x, d, r), div_shared(a.y, d, r), div_shared(a.z, d, r)};
+    }
+    return D3{a.x / d, a.y / d, a.z / d};
+}
+
 // |x| == 0 or 2^-300 <= |x| <= 2^300 (false for NaN / inf)
 RT_DEV bool in_window(double x) {
     double ax = fabs(x);
@@ -255,6 +270,16 @@ RT_DEV bool cylinder_t(const double* cy, D3 o, D3 dir, double& t_out, int& part_
     t_out = t;
     part_out = part;
     return hit;
+}
+
+// One value of a lane's row of 16 lanes to a partner lane, as a data-parallel-primitive move (no LDS round trip):
+// kCtrl 0xB1 / 0x4E = quad_perm [1,0,3,2] / [2,3,0,1] (lane ^ 1, lane ^ 2), 0x141 = row_half_mirror (7 - lane within
+// 8 lanes), 0x140 = row_mirror (15 - lane within the row).
+template <int kCtrl>
+RT_DEV double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
 
 // Philox4x32-10 and the uniform stream of DESIGN.md "RNG" (same definition as oracle/oracle.cpp,

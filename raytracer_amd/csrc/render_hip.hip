@@ -193,6 +193,8 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 8: r = div_shared(x, y, refine_rcp(y)); break;  // exact division through a shared reciprocal
         case 9: r = normalize(mk(x, y, 0.75 * y)).x; break;  // Vector3::normalize (shared reciprocal when it is exact)
         case 10: r = normalize(mk(y, 0.75 * y, x)).z; break;
+        case 11: r = div3(mk(x, 0.75 * x, -1.5 * x), y).x; break;  // D3 / double through one shared reciprocal when exact
+        case 12: r = div3(mk(0.75 * x, -1.5 * x, x), y).z; break;
         default: r = 0.0;
     }
     out[k] = r;
@@ -256,6 +258,7 @@ struct rt_context {
     int bw_info_blocks = 0;
     unsigned long long generation = 1;  // bumped by upload / set_camera / set_params
     int n_point_lights = 0, n_area_lights = 0;
+    DLight light0;  // host copy of the first light: pt_kernel takes it as a kernel argument
     // wavefront node store
     double* d_wf_nodes = nullptr;
     int* d_wf_alive = nullptr;
@@ -682,6 +685,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         d.reflective = m.is_reflective;
         d.refractive = m.is_refractive;
         d.texture = m.texture;
+        const double norm = (m.specular_exponent + 2.0) / (2.0 * M_PI);
+        for (int k = 0; k < 3; ++k) d.spec_brdf[k] = m.specular[k] * m.ks * norm;
     }
     std::vector<int> mat_of_gid(s->prim_material, s->prim_material + s->n_prims);
     std::vector<DLight> lights(s->n_lights);
@@ -732,6 +737,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     std::memcpy(sv.bg, s->background, sizeof sv.bg);
     c->sv = sv;
     c->n_bvh_nodes = sv.n_nodes;
+    std::memset(&c->light0, 0, sizeof c->light0);
+    if (!lights.empty()) c->light0 = lights[0];
     c->n_point_lights = c->n_area_lights = 0;
     for (int i = 0; i < s->n_lights; ++i) (s->lights[i].type == RT_LIGHT_POINT ? c->n_point_lights : c->n_area_lights)++;
     ++c->generation;

@@ -68,6 +68,7 @@ struct DMaterial {
     double diffuse[3];
     double specular[3];
     int spec_exp, reflective, refractive, texture;
+    double spec_brdf[3];  // specular * ks * ((exp + 2) / (2 pi)), the sample-independent part of RayTracer.cpp:624 / :668
 };
 struct DLight {
     int type, pad;
@@ -513,11 +514,18 @@ RT_DEV int gid_of_ref(P img, const SceneView& sv, int ref) {
 // Material of a primitive: two reads of the scene image (LDS when it is staged) instead of a dependent
 // chain of global loads per shaded hit.
 template <typename P>
-RT_DEV const DMaterial& material_of(P img, const SceneView& sv, int ref) {
-    const int mi = ((const int*)(img + sv.off_matidx))[gid_of_ref(img, sv, ref)];
+RT_DEV int material_index(P img, const SceneView& sv, int ref) {
+    return ((const int*)(img + sv.off_matidx))[gid_of_ref(img, sv, ref)];
+}
+template <typename P>
+RT_DEV const DMaterial& material_at(P img, const SceneView& sv, int mi) {
     // the records themselves are in the staged part only when they fit next to the geometry
     const unsigned char* base = sv.mat_staged ? img + 0 : sv.image;
     return *(const DMaterial*)(base + sv.off_mat + mi * (int)sizeof(DMaterial));
+}
+template <typename P>
+RT_DEV const DMaterial& material_of(P img, const SceneView& sv, int ref) {
+    return material_at(img, sv, material_index(img, sv, ref));
 }
 
 // point and normal of the winning primitive, computed from t exactly as the intersect functions
@@ -995,6 +1003,7 @@ RT_DEV D3 hemisphere(D3 n, double r1, double r2) {  // randomInHemisphere, RayTr
 }
 
 // AreaLight::sample (src/AreaLight.cpp:3-20) for sample `si` of light `li` at RNG node `node`
+template <bool kShared = false>  // kShared: ldir / distance through div3 (same bits)
 RT_DEV void area_sample(const RenderArgs& A, const DLight& Lt, const Rng& rng, unsigned node, int li, int si, D3 point,
                         D3& ldir, double& distance, double& pdf) {
     unsigned dim = DIM_LIGHT0 + 2u * (unsigned)(li * A.light_samples + si);
@@ -1003,7 +1012,7 @@ RT_DEV void area_sample(const RenderArgs& A, const DLight& Lt, const Rng& rng, u
     D3 sp = ld3(Lt.position) + ld3(Lt.u) * su + ld3(Lt.v) * sv;
     ldir = sp - point;
     distance = length(ldir);
-    ldir = ldir / distance;
+    ldir = kShared ? div3(ldir, distance) : ldir / distance;
     double area = Lt.width * Lt.height;
     double cosine = std_max(0.0, dot(ld3(Lt.normal), -ldir));
     pdf = (distance * distance) / (area * cosine);

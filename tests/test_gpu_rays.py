@@ -81,6 +81,32 @@ def test_normalize_shares_one_reciprocal_exactly(renderer):
     assert np.array_equal(np.signbit(got), np.signbit(ez))
 
 
+def test_vector_over_scalar_shares_one_reciprocal_exactly(renderer):
+    """device_math.hpp div3 (Vector3 / double: AreaLight.cpp:13, RayTracer.cpp:678): one refined reciprocal for the
+    three quotients when no operand can need v_div_scale's scaling, the literal divisions otherwise -- either way
+    the correctly rounded IEEE quotients."""
+    rng = np.random.default_rng(23)
+    n = 3_000_000
+    x = rng.standard_normal(n) * np.exp2(rng.uniform(-40, 40, n))
+    d = rng.standard_normal(n) * np.exp2(rng.uniform(-40, 40, n))
+    k = 300_000
+    x[:k] = rng.standard_normal(k) * np.exp2(rng.uniform(-350, 350, k))   # around and beyond the guard's limits
+    d[:k] = rng.standard_normal(k) * np.exp2(rng.uniform(-350, 350, k))
+    x[k:k + 1000] = 0.0
+    d[k + 500:k + 1500] = 0.0
+    x[2 * k:3 * k] = np.frombuffer((np.uint64(0x3FEFFFFFFFFFFFFF) - rng.integers(0, 4, k).astype(np.uint64)).tobytes(), dtype=np.float64)
+    d[3 * k:4 * k] = np.frombuffer((np.uint64(0x3FF0000000000000) + rng.integers(0, 4, k).astype(np.uint64)).tobytes(), dtype=np.float64)
+    x[-5:] = [np.inf, 1e-320, 1e300, -0.0, np.nan]
+    d[-5:] = [1.0, 1e-320, 1e-300, 1.0, 1.0]
+    with np.errstate(all="ignore"):
+        e = x / d
+    for op in (11, 12):
+        got = renderer.math(op, x, d)
+        assert np.array_equal(got, e, equal_nan=True)
+        finite = ~np.isnan(e)
+        assert np.array_equal(np.signbit(got[finite]), np.signbit(e[finite]))
+
+
 def test_transcendentals_within_a_few_ulp(renderer):
     """pow/atan2/acos/cos/sin of the device library are not bit-identical to glibc; the contract only
     needs colours within 1e-4.  Measured: <= 2 ulp."""
