@@ -81,7 +81,10 @@ int main(int argc, char* argv[]) {
     }
     std::cout << "\rRendering: 100% completed" << std::flush;
     rt_stats st;
-    rt_get_stats(ctx, &st);
+    if (rt_get_stats(ctx, &st) != RT_OK) {
+        std::cerr << "Error: " << rt_last_error() << std::endl;
+        return 1;
+    }
     if (rt_write_ppm_u8(out_path.c_str(), rgb.data(), params.width, params.height) != RT_OK) {
         std::cerr << "Error: " << rt_last_error() << std::endl;
         return 1;

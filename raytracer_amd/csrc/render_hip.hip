@@ -264,12 +264,21 @@ struct rt_context {
     int* d_wf_alive = nullptr;
     unsigned char* d_wf_shadow = nullptr;
     void* d_wf_state = nullptr;
+    // Overflow flag of the per-workgroup pipelines (fused / block / path / grid): ONE word of pinned, device-mapped
+    // host memory.  A kernel whose arena was too small sets it; the host reads it without any HIP call, so every
+    // entry point can check it: the blocking ones after their copy (and render the frame again), the
+    // asynchronous ones at the next call on the context (the flag stays set until the host has seen it).
+    unsigned* h_overflow = nullptr;  // host address
+    unsigned* d_overflow = nullptr;  // the same word as the device sees it
+    long long debug_cap = 0;         // RT_WF_DEBUG_CAP: initial node capacity of an unsized setup (tests force growth)
+    double debug_shrink = 0.0;       // RT_WF_DEBUG_SHRINK: factor applied ONCE to a measured capacity (tests force a later overflow)
     long long wf_cap = 0;
     size_t wf_shadow_bytes = 0;
     unsigned long long wf_calibrated_gen = 0;
     long long wf_needed_cap = 0;
     int wf_batch = 1, wf_levels_used = 0;
     bool last_was_wavefront = false;
+    bool overflow_reported = false;  // the last RT_ERR_LIMIT of launch_* reported an EARLIER frame's overflow (this one was not rendered)
 };
 
 namespace {
@@ -421,6 +430,47 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     return RT_OK;
 }
 
+// After the device has finished the last frame (the caller has synchronized): did it flag an arena that was too
+// small?  Clears the flag and forgets the measured capacities, so that the next render sizes the store again.
+int frame_overflowed(rt_context* c, bool* out) {
+    *out = false;
+    if (!c->last_was_wavefront || c->params.max_depth <= 0) return RT_OK;
+    unsigned overflow = 0;
+    if (c->level_kernels) {
+        if (!c->d_wf_state) return RT_OK;
+        WfState st;
+        HIP_TRY(hipMemcpy(&st, c->d_wf_state, sizeof st, hipMemcpyDeviceToHost));
+        overflow = st.overflow;
+    } else {
+        overflow = *(volatile unsigned*)c->h_overflow;
+        *(volatile unsigned*)c->h_overflow = 0;
+    }
+    if (overflow) {
+        c->wf_calibrated_gen = 0;
+        *out = true;
+    }
+    return RT_OK;
+}
+
+// Blocking entry points: launch, wait, and render the frame again (sizing the node store anew) if a capacity
+// measured on an earlier frame turned out too small for this one.
+template <typename Launch>
+int render_until_it_fits(rt_context* c, Launch launch) {
+    for (int attempt = 0;; ++attempt) {
+        int rc = launch();
+        if (rc == RT_ERR_LIMIT && c->overflow_reported && attempt < 4) {  // an earlier asynchronous frame's flag: sized anew, go on
+            c->overflow_reported = false;
+            continue;
+        }
+        if (rc != RT_OK) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        bool again = false;
+        if ((rc = frame_overflowed(c, &again)) != RT_OK) return rc;
+        if (!again) return RT_OK;
+        if (attempt >= 4) return rt::set_error(RT_ERR_LIMIT, "render: the node store overflowed %d times in a row", attempt + 1);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -458,6 +508,8 @@ int rt_create(rt_context** out, int device) {
     c->gridwave = pipe && std::strcmp(pipe, "grid") == 0;
     if (const char* e = std::getenv("RT_SPLIT_ROOTS")) c->split_roots = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_PT_GENERIC")) c->pt_generic = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_WF_DEBUG_CAP")) c->debug_cap = std::max(0ll, std::atoll(e));
+    if (const char* e = std::getenv("RT_WF_DEBUG_SHRINK")) c->debug_shrink = std::atof(e);
     c->n_cus = prop.multiProcessorCount;
     if (const char* e = std::getenv("RT_WORKGROUPS")) c->max_workgroups = std::max(0, std::atoi(e));
     std::memset(&c->sv, 0, sizeof c->sv);
@@ -465,7 +517,10 @@ int rt_create(rt_context** out, int device) {
     hipError_t b = hipMalloc((void**)&c->d_counters, (size_t)kCounterSlots * kCounterRow * sizeof(unsigned long long));
     hipError_t s0 = hipEventCreate(&c->ev_start);
     hipError_t s1 = hipEventCreate(&c->ev_stop);
-    if (a != hipSuccess || b != hipSuccess || s0 != hipSuccess || s1 != hipSuccess) {
+    hipError_t h0 = hipHostMalloc((void**)&c->h_overflow, sizeof(unsigned), hipHostMallocMapped);
+    hipError_t h1 = h0 == hipSuccess ? hipHostGetDevicePointer((void**)&c->d_overflow, c->h_overflow, 0) : h0;
+    if (h1 == hipSuccess) *c->h_overflow = 0;
+    if (a != hipSuccess || b != hipSuccess || s0 != hipSuccess || s1 != hipSuccess || h1 != hipSuccess) {
         rt_destroy(c);
         return rt::set_error(RT_ERR_DEVICE, "rt_create: device allocation failed");
     }
@@ -490,6 +545,7 @@ void rt_destroy(rt_context* c) {
     (void)hipFree(c->d_gw_timing);
     (void)hipFree(c->d_ticket);
     (void)hipFree(c->d_counters);
+    if (c->h_overflow) (void)hipHostFree(c->h_overflow);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -862,7 +918,9 @@ int rt_render_u8(rt_context* c, uint8_t* rgb8, int32_t* hit_id) {
         release();
         return rt::set_error(RT_ERR_DEVICE, "rt_render_u8: hipMalloc -> %s", hipGetErrorString(e));
     }
-    int rc = pt ? launch_render(c, nullptr, d_rgb, d_hit, false) : launch_render(c, nullptr, nullptr, d_hit, false, d_u8);
+    int rc = render_until_it_fits(c, [&]() {
+        return pt ? launch_render(c, nullptr, d_rgb, d_hit, false) : launch_render(c, nullptr, nullptr, d_hit, false, d_u8);
+    });
     if (rc == RT_OK && pt) rc = rt_quantize_device(c, nullptr, d_rgb, (int64_t)n_px * 3, d_u8);
     if (rc == RT_OK) {
         e = hipMemcpy(rgb8, d_u8, n_px * 3, hipMemcpyDeviceToHost);
@@ -889,7 +947,7 @@ int rt_render(rt_context* c, double* rgb, int32_t* hit_id) {
         }
         (void)hipMemset(d_hit, 0xFF, std::max<size_t>(n_px, 1) * sizeof(int));
     }
-    int rc = launch_render(c, nullptr, d_rgb, d_hit, false);
+    int rc = render_until_it_fits(c, [&]() { return launch_render(c, nullptr, d_rgb, d_hit, false); });
     if (rc == RT_OK) {
         hipError_t e = hipMemcpy(rgb, d_rgb, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost);
         if (e == hipSuccess && hit_id) e = hipMemcpy(hit_id, d_hit, n_px * sizeof(int), hipMemcpyDeviceToHost);
@@ -920,20 +978,11 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
         out->triangle_tests = cnt[3];
         out->cylinder_tests = cnt[4];
         out->prim_tests = cnt[2] + cnt[3] + cnt[4];
-        if (c->last_was_wavefront && c->d_wf_state && c->params.max_depth > 0) {
-            unsigned overflow = 0;
-            if (c->level_kernels) {
-                WfState st;
-                HIP_TRY(hipMemcpy(&st, c->d_wf_state, sizeof st, hipMemcpyDeviceToHost));
-                overflow = st.overflow;
-            } else {
-                HIP_TRY(hipMemcpy(&overflow, c->d_wf_state, sizeof overflow, hipMemcpyDeviceToHost));
-            }
-            if (overflow) {
-                c->wf_calibrated_gen = 0;  // recalibrate on the next render
-                return rt::set_error(RT_ERR_LIMIT, "the last render overflowed its node store; its output is invalid, render again");
-            }
-        }
+        bool overflowed = false;
+        int rc = frame_overflowed(c, &overflowed);
+        if (rc != RT_OK) return rc;
+        if (overflowed)
+            return rt::set_error(RT_ERR_LIMIT, "the last render overflowed its node store; its output is invalid, render again");
     }
     out->upload_ms = c->upload_ms;
     out->n_bvh_nodes = c->n_bvh_nodes;
