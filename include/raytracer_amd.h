@@ -282,6 +282,11 @@ int rt_debug_trace_rays(rt_context* ctx, int64_t n, const double* origins, const
  * normalize((a, b, 0.75 b)) (of normalize((b, 0.75 b, a))), 11 / 12 the x (z) component of (a, 0.75 a, -1.5 a) / b
  * (of (0.75 a, -1.5 a, a) / b) through the shared-reciprocal Vector3 / double. */
 int rt_debug_math(rt_context* ctx, int op, int64_t n, const double* a, const double* b, double* out);
+/* op 0: n rows in[k] = (I xyz, N xyz, eta_t, eta_i) -> out[k] = (refract xyz, 1 if length(normalize(refract)) > 0 else 0
+ * [the transmission test of RayTracer.cpp:572], reflect xyz, fresnel, fresnelReflectance(|I.N|, eta_t)), the device's
+ * restatement of RayTracer.cpp:430-504.  op 1: n rows of colours (3) -> toneMap for NONE, REINHARD, WARD, UNCHARTED2 (12),
+ * RayTracer.cpp:161-202.  Checked against the reference's own functions (tests/golden/unit_vectors.npz). */
+int rt_debug_optics(rt_context* ctx, int op, int64_t n, const double* in, double* out);
 
 #ifdef __cplusplus
 }

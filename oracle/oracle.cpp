@@ -978,6 +978,25 @@ void oracle_tonemap(const double in[3], int tm, double out[3]) {
     out[0] = c.x; out[1] = c.y; out[2] = c.z;
 }
 
+// reflect / refract / fresnel / fresnelReflectance (RayTracer.cpp:430-504) on n rows of (I xyz, N xyz, eta_t, eta_i):
+// out row = refract xyz, [length(normalize(refract)) > 0] (the transmission test of :572), reflect xyz, fresnel,
+// fresnelReflectance(|I.N|, eta_t).  Checked against the reference's own functions (tests/golden/unit_vectors.npz).
+void oracle_optics(int64_t n, const double* in, double* out) {
+    for (int64_t k = 0; k < n; ++k) {
+        const double* r = in + 8 * k;
+        double* o = out + 9 * k;
+        V3 I(r), N(r + 3);
+        V3 t = Renderer::refract(I, N, r[6], r[7]);
+        V3 tn = normalize(t);
+        V3 rf = Renderer::reflect(I, N);
+        o[0] = t.x; o[1] = t.y; o[2] = t.z;
+        o[3] = length(tn) > 0.0 ? 1.0 : 0.0;
+        o[4] = rf.x; o[5] = rf.y; o[6] = rf.z;
+        o[7] = Renderer::fresnel(I, N, r[6], r[7]);
+        o[8] = Renderer::schlick(std::fabs(dot(I, N)), r[6]);
+    }
+}
+
 void oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 
 double oracle_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t dim) {

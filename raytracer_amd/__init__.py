@@ -154,6 +154,13 @@ class Renderer:
                    "rt_debug_math")
         return out
 
+    def optics(self, op, rows):
+        """rt_debug_optics: op 0 rows [n, 8] -> [n, 9], op 1 colours [n, 3] -> [n, 12]."""
+        a = np.ascontiguousarray(rows, dtype=np.float64)
+        out = np.empty((a.shape[0], 9 if op == 0 else 12), dtype=np.float64)
+        capi.check(self._lib.rt_debug_optics(self._h, op, a.shape[0], a.ctypes.data, out.ctypes.data), "rt_debug_optics")
+        return out
+
     def close(self):
         if self._h:
             self._lib.rt_destroy(self._h)

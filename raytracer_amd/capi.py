@@ -116,6 +116,7 @@ SYMBOLS = {
     "rt_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
     "rt_debug_trace_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_math": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_debug_optics": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -538,11 +538,16 @@ int write_p3(const char* path, const Row* data, int32_t width, int32_t height, V
     char digits[256][4];
     int dlen[256];
     for (int v = 0; v < 256; ++v) dlen[v] = std::snprintf(digits[v], 4, "%d", v);
-    std::vector<char> line((size_t)width * 12 + 16);
+    // a component prints at most 11 characters ("-2147483648": out-of-range or NaN input) plus its separator
+    std::vector<char> line(std::max<size_t>((size_t)width * 12, 64) + 64);
     for (int j = height - 1; j >= 0; --j) {
         char* p = line.data();
         const Row* row = data + (size_t)j * width * 3;
         for (int i = 0; i < width; ++i) {
+            if ((size_t)(p - line.data()) + 40 > line.size()) {  // room for one whole pixel, whatever its values
+                std::fwrite(line.data(), 1, (size_t)(p - line.data()), fp);
+                p = line.data();
+            }
             for (int c = 0; c < 3; ++c) {
                 int v = value(row[i * 3 + c]);
                 if (v >= 0 && v < 256) {
@@ -552,10 +557,6 @@ int write_p3(const char* path, const Row* data, int32_t width, int32_t height, V
                     p += std::sprintf(p, "%d", v);  // out-of-range input; the reference prints it too
                 }
                 *p++ = (c == 2) ? '\n' : ' ';
-            }
-            if ((size_t)(p - line.data()) + 64 > line.size()) {
-                std::fwrite(line.data(), 1, (size_t)(p - line.data()), fp);
-                p = line.data();
             }
         }
         std::fwrite(line.data(), 1, (size_t)(p - line.data()), fp);

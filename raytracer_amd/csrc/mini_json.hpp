@@ -107,6 +107,13 @@ public:
 private:
     const char* p_;
     const char* end_;
+    int depth_ = 0;  // nesting of objects / arrays: capped so that a hostile file cannot overflow the stack
+    static constexpr int kMaxDepth = 256;
+    struct Nest {
+        Parser& p;
+        explicit Nest(Parser& q) : p(q) { if (++p.depth_ > kMaxDepth) p.fail("nesting deeper than 256 levels"); }
+        ~Nest() { --p.depth_; }
+    };
 
     [[noreturn]] void fail(const char* what) const { throw std::runtime_error(std::string("json parse error: ") + what); }
     void skip_ws() {
@@ -126,8 +133,8 @@ private:
         if (p_ == end_) fail("unexpected end of input");
         Value v;
         switch (*p_) {
-            case '{': return parse_object();
-            case '[': return parse_array();
+            case '{': { Nest n(*this); return parse_object(); }
+            case '[': { Nest n(*this); return parse_array(); }
             case '"':
                 v.kind = Value::String;
                 v.s = parse_string();

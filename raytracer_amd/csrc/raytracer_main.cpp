@@ -4,7 +4,10 @@
 // (/root/reference/src/RayTracer.cpp:42-159); the render itself goes to the GPU through the
 // C-ABI in include/raytracer_amd.h.  Optional environment variables (no effect on the original
 // invocation): RT_DEVICE (GPU ordinal), RT_WIDTH / RT_HEIGHT (override camera.width/height; the
-// aspect ratio of the camera follows, as it would after editing the JSON), RT_SEED.
+// aspect ratio of the camera follows, as it would after editing the JSON), RT_SEED, and for path tracing
+// RT_FIX_SAMPLE_SWAP=1 (undo the reference's swap at RayTracer.cpp:138-139: JSON "pixelsample" then means
+// samples per pixel and "lightsample" samples per light), RT_PIXEL_SAMPLES / RT_LIGHT_SAMPLES (set
+// RayTracer::pixelSamples / lightSamples directly, after the swap or its undoing).
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -12,6 +15,7 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "raytracer_amd.h"
@@ -32,11 +36,7 @@ int main(int argc, char* argv[]) {
     std::cout << "Parsing scene settings..." << std::endl;
     rt_scene_file* file = nullptr;
     int rc = rt_scene_file_load(json_path.c_str(), argc == 4 ? argv[3] : nullptr, &file);
-    if (rc == RT_ERR_IO && !file) {
-        // "Could not open JSON file" was already printed by the loader when that was the cause
-        std::cerr << rt_last_error() << std::endl;
-        return 1;
-    }
+    if (rc == RT_ERR_IO && !file) return 1;  // the loader has printed "Error: Could not open JSON file ..." (RayTracer.cpp:58)
     if (rc != RT_OK) {
         std::cerr << "Error: " << rt_last_error() << std::endl;
         return 1;
@@ -55,6 +55,11 @@ int main(int argc, char* argv[]) {
     rt_params params = *rt_scene_file_params(file);
     rt_camera camera = *rt_scene_file_camera(file);
     if (desc->use_bvh) std::cout << "Building BVH..." << std::endl;
+    if (params.mode == RT_MODE_PATHTRACE) {
+        if (env_int("RT_FIX_SAMPLE_SWAP", 0) != 0) std::swap(params.pixel_samples, params.light_samples);
+        params.pixel_samples = env_int("RT_PIXEL_SAMPLES", params.pixel_samples);
+        params.light_samples = env_int("RT_LIGHT_SAMPLES", params.light_samples);
+    }
     const char* seed_env = std::getenv("RT_SEED");
     if (seed_env && *seed_env) params.seed = std::strtoull(seed_env, nullptr, 10);
 

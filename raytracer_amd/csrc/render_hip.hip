@@ -170,6 +170,34 @@ __global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const do
     }
 }
 
+// rows of (I, N, eta_t, eta_i) -> (refract, transmits, reflect, fresnel, fresnelReflectance); rows of colours -> the
+// four tone maps: the device functions of RayTracer.cpp:430-504 and :161-202 on chosen inputs
+__global__ void debug_optics_kernel(int op, long long n, const double* in, double* out) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (op == 0) {
+        const double* r = in + 8 * k;
+        double* o = out + 9 * k;
+        D3 I = ld3(r), N = ld3(r + 3);
+        D3 t = refract_v(I, N, r[6], r[7]);
+        D3 tn = normalize(t);
+        D3 rf = reflect_v(I, N);
+        o[0] = t.x; o[1] = t.y; o[2] = t.z;
+        o[3] = length(tn) > 0.0 ? 1.0 : 0.0;
+        o[4] = rf.x; o[5] = rf.y; o[6] = rf.z;
+        o[7] = fresnel_f(I, N, r[6], r[7]);
+        o[8] = schlick(fabs(dot(I, N)), r[6]);
+    } else {
+        D3 c = ld3(in + 3 * k);
+        for (int tm = 0; tm < 4; ++tm) {
+            D3 v = tone_map(c, tm);
+            out[12 * k + 3 * tm] = v.x;
+            out[12 * k + 3 * tm + 1] = v.y;
+            out[12 * k + 3 * tm + 2] = v.z;
+        }
+    }
+}
+
 __global__ void debug_math_kernel(int op, long long n, const double* a, const double* b, double* out) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -627,6 +655,17 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     // Image layout: first what every ray of the filter-BVH traversal touches (staged into LDS), then the
     // reference tree and the linear-scan table, which that traversal only reads for the rare rays it
     // hands to the exact walk (from the global copy).  The other traversal modes stage everything.
+    // (sizes in 64 bits: ~370 B per primitive wrap a 32-bit sum near 5 M primitives, and the offsets below are ints)
+    long long total_bytes = 0;
+    {
+        const long long np = s->n_prims;
+        total_bytes += fb.ok ? (long long)fb.n_nodes * kFNodeBytes + np * kLeafBytes : 0;
+        total_bytes += ((long long)sph.size() + (long long)tri.size() + (long long)cyl.size()) * 8;
+        total_bytes += np * 4 * 3 + (long long)s->n_materials * (long long)sizeof(DMaterial);
+        total_bytes += (long long)sv.n_nodes * kNodeBytes + 16 * 16;
+        if (total_bytes >= 0x7FFFFFFFll)
+            return rt::set_error(RT_ERR_LIMIT, "rt_upload_scene: scene image of %lld bytes exceeds the 2 GB the 32-bit offsets address", total_bytes);
+    }
     int off = 0;
     if (fb.ok) {
         sv.off_fnodes = off;   off = align16(off + fb.n_nodes * kFNodeBytes);
@@ -1021,6 +1060,26 @@ int rt_debug_trace_rays(rt_context* c, int64_t n, const double* origins, const d
     if (e == hipSuccess) e = hipMemcpy(normal_out, d_n, v3, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = rt::set_error(RT_ERR_DEVICE, "rt_debug_trace_rays -> %s", hipGetErrorString(e));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_n); (void)hipFree(d_p);
+    return rc;
+}
+
+int rt_debug_optics(rt_context* c, int op, int64_t n, const double* in, double* out) {
+    if (!c || n < 0 || !in || !out || op < 0 || op > 1) return rt::set_error(RT_ERR_INVALID, "rt_debug_optics: bad argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)n * (op == 0 ? 8 : 3) * sizeof(double), out_bytes = (size_t)n * (op == 0 ? 9 : 12) * sizeof(double);
+    double *d_in = nullptr, *d_out = nullptr;
+    int rc = RT_OK;
+    hipError_t e = hipMalloc((void**)&d_in, in_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(debug_optics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, (long long)n, d_in, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = rt::set_error(RT_ERR_DEVICE, "rt_debug_optics -> %s", hipGetErrorString(e));
+    (void)hipFree(d_in); (void)hipFree(d_out);
     return rc;
 }
 

@@ -35,6 +35,8 @@ def load():
         lib.oracle_uniform.restype = C.c_double
         lib.oracle_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.oracle_max_threads.restype = C.c_int
+        lib.oracle_optics.restype = None
+        lib.oracle_optics.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -65,3 +67,29 @@ def trace_rays(desc, origins, dirs):
     lib.oracle_trace_rays(C.byref(desc), n, o.ctypes.data, d.ctypes.data, t.ctypes.data, prim.ctypes.data,
                           nrm.ctypes.data)
     return t, prim, nrm
+
+
+def optics(rows):
+    """rows [n, 8] = I, N, eta_t, eta_i -> [n, 9] = refract, transmits, reflect, fresnel, fresnelReflectance."""
+    a = np.ascontiguousarray(rows, dtype=np.float64)
+    out = np.zeros((a.shape[0], 9), dtype=np.float64)
+    load().oracle_optics(a.shape[0], a.ctypes.data, out.ctypes.data)
+    return out
+
+
+def tonemap(colours):
+    """colours [n, 3] -> [n, 12]: toneMap for NONE, REINHARD, WARD, UNCHARTED2."""
+    a = np.ascontiguousarray(colours, dtype=np.float64)
+    out = np.zeros((a.shape[0], 12), dtype=np.float64)
+    lib = load()
+    for k in range(a.shape[0]):
+        for tm in range(4):
+            lib.oracle_tonemap(a[k].ctypes.data, tm, out[k, 3 * tm:3 * tm + 3].ctypes.data)
+    return out
+
+
+def box_hit(box_lo_hi, origin, direction):
+    b = np.ascontiguousarray(box_lo_hi, dtype=np.float64)
+    o = np.ascontiguousarray(origin, dtype=np.float64)
+    d = np.ascontiguousarray(direction, dtype=np.float64)
+    return bool(load().oracle_box_hit(b.ctypes.data, o.ctypes.data, d.ctypes.data))

@@ -431,6 +431,46 @@ def test_cli_writes_the_reference_file(name, tonemap, ref_outputs, tmp_path):
     assert hashlib.sha256(out.read_bytes()).hexdigest() == ref_outputs[name]["sha256"]
 
 
+def test_cli_environment_overrides(renderer, tmp_path):
+    """RT_WIDTH / RT_HEIGHT, RT_PIXEL_SAMPLES / RT_LIGHT_SAMPLES and RT_FIX_SAMPLE_SWAP leave the
+    original invocation alone and give the file the library renders with those parameters."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracer_amd", "csrc", "raytracer")
+
+    def cli(scene, env):
+        out = tmp_path / "o.ppm"
+        res = subprocess.run([exe, os.path.join("scenes", scene + ".json"), str(out)], cwd=ROOT, capture_output=True, text=True,
+                             timeout=120, env=dict(os.environ, **env))
+        assert res.returncode == 0, res.stderr
+        return out.read_bytes(), res.stdout
+
+    def lib(sf, P):
+        renderer.load(sf, P)
+        u8, _ = renderer.render_u8()
+        ref = tmp_path / "ref.ppm"
+        rt.write_ppm_u8(ref, u8)
+        return ref.read_bytes()
+
+    sf = scene_util.load("blinn_phong", 300, 200)
+    got, _ = cli("blinn_phong", {"RT_WIDTH": "300", "RT_HEIGHT": "200"})
+    assert got == lib(sf, sf.params)
+    # path trace: pathtrace.json has neither sample key -> pixelSamples 4, lightSamples 16 after the reference's swap
+    sf = scene_util.load("pathtrace", 60, 40)
+    small = {"RT_WIDTH": "60", "RT_HEIGHT": "40"}
+    got, out = cli("pathtrace", small)
+    assert "Pixel samples: 4" in out and "Light samples: 16" in out
+    assert got == lib(sf, sf.params)
+    got, out = cli("pathtrace", dict(small, RT_FIX_SAMPLE_SWAP="1"))
+    assert "Pixel samples: 16" in out and "Light samples: 4" in out
+    P = sf.params
+    P.pixel_samples, P.light_samples = 16, 4
+    assert got == lib(sf, P)
+    got, out = cli("pathtrace", dict(small, RT_PIXEL_SAMPLES="9", RT_LIGHT_SAMPLES="2", RT_SEED="7"))
+    assert "Pixel samples: 9" in out and "Light samples: 2" in out
+    P.pixel_samples, P.light_samples, P.seed = 9, 2, 7
+    assert got == lib(sf, P)
+
+
 def test_render_u8_is_the_quantized_frame(renderer, tmp_path):
     """rt_render_u8 / rt_write_ppm_u8 == rt_render + rt_write_ppm, Whitted and path-traced."""
     for name, mode in (("clutter_500", None), ("pathtrace", rt.RT_MODE_PATHTRACE)):

@@ -121,3 +121,34 @@ def test_ppm_writer_format(tmp_path):
     assert lines[3 + 2] == "255 0 255"   # top row first (j = H-1), third pixel; int(255.999*0.999) = 255
     assert lines[3 + 3] == "255 127 0"   # then the bottom row
     assert lines[-1] == "" and len(lines) == 3 + 6 + 1
+
+
+def test_ppm_writer_survives_out_of_range_values(tmp_path):
+    """a 1-pixel-wide image of NaN / huge values prints 11 characters per component, as the
+    reference's operator<< would ("-2147483648" for int(255.999 * NaN) on x86-64); the line buffer must hold it."""
+    rgb = np.array([[[np.nan, -1e300, 1e300]], [[-3.0, 2.0, 0.5]]])
+    p = os.path.join(str(tmp_path), "w1.ppm")
+    rt.write_ppm(p, rgb)
+    lines = open(p).read().split("\n")
+    assert lines[:3] == ["P3", "1 2", "255"]
+    assert lines[3] == "-767 511 127"                      # top row first: int(255.999 * c), no clamping in the writer
+    assert lines[4] == "-2147483648 -2147483648 -2147483648"
+
+
+def test_json_nesting_depth_is_capped(tmp_path):
+    p = os.path.join(str(tmp_path), "deep.json")
+    open(p, "w").write("[" * 100000 + "]" * 100000)
+    with pytest.raises(rt.RtError):
+        rt.SceneFile(p)
+
+
+def test_cli_usage_and_missing_file_messages(tmp_path):
+    """Exit codes and messages of main() before the seam (RayTracer.cpp:47-60); no GPU needed to get there."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "csrc", "raytracer")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 1 and "Usage: raytracer.exe path_to_JSON output_filename.ppm" in res.stderr
+    res = subprocess.run([exe, os.path.join(str(tmp_path), "nope.json"), os.path.join(str(tmp_path), "o.ppm")],
+                         capture_output=True, text=True, timeout=60)
+    assert res.returncode == 1
+    assert res.stderr.count("Could not open JSON file") + res.stderr.count("could not open JSON file") == 1  # once, as the reference
