@@ -268,6 +268,29 @@ int rt_pathtrace_resolve_device(rt_context* ctx, void* stream, double* accum_dev
 /* Blocks until the last render on this context finished, then fills stats. */
 int rt_get_stats(rt_context* ctx, rt_stats* out);
 
+/* ---- several GPUs of one node behind the same seam ------------------------------------------
+ * The reference's seam is ONE blocking call (RayTracer.cpp:146-149); a group is what stands behind it when the
+ * caller names more than one device ("create context (takes device list)").  One process, one
+ * rt_context + stream per device, the scene replicated; a frame is partitioned as SURVEY.md 8(e) lays out --
+ * Whitted / binary: 8-row bands dealt round-robin, each member's bands copied into the frame on devices[0] by one
+ * strided peer copy over xGMI (as PPM bytes for rt_group_render_u8); path trace: strata ranges, the members' radiance
+ * sums added on devices[0] in member order before the non-linear stages of RayTracer.cpp:301-315.  The frame equals the
+ * one-device frame (bit for bit for Whitted; to fp summation order, ~1e-16 relative, for path-trace sums).
+ * The same device may be listed more than once (members then share it).  Pass whole-frame params. */
+typedef struct rt_group rt_group;
+int rt_group_create(rt_group** out, const int* devices, int n_devices);
+void rt_group_destroy(rt_group* g);
+int rt_group_size(const rt_group* g);
+int rt_group_upload_scene(rt_group* g, const rt_scene_desc* scene);
+int rt_group_set_camera(rt_group* g, const rt_camera* cam);
+int rt_group_set_params(rt_group* g, const rt_params* p);
+/* rt_render / rt_render_u8 for the group: blocking, the whole frame into host buffers (3*W*H doubles / bytes, and
+ * optionally W*H primary-hit ids; path-traced frames report -1 as rt_render does not report ids for them either). */
+int rt_group_render(rt_group* g, double* rgb, int32_t* hit_id);
+int rt_group_render_u8(rt_group* g, uint8_t* rgb8, int32_t* hit_id);
+/* Sums of the members' counters; kernel_ms = the slowest member (they render side by side). */
+int rt_group_get_stats(rt_group* g, rt_stats* out);
+
 /* ---- diagnostics ---------------------------------------------------------------------------
  * No counterpart in the reference: per-function hooks so that the parity tests can drive
  * Scene::intersect (src/Scene.cpp:63-81) and the device math library on chosen inputs. */

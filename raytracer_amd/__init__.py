@@ -13,7 +13,7 @@ from . import capi
 from .capi import (RT_MODE_BINARY, RT_MODE_PATHTRACE, RT_MODE_PHONG, RT_TONEMAP_NONE,  # noqa: F401
                    RT_TONEMAP_REINHARD, RT_TONEMAP_UNCHARTED2, RT_TONEMAP_WARD, RtError)
 
-__all__ = ["SceneFile", "Renderer", "capi", "RtError", "copy_params"]
+__all__ = ["SceneFile", "Renderer", "Group", "capi", "RtError", "copy_params"]
 
 
 def copy_params(p):
@@ -164,6 +164,54 @@ class Renderer:
     def close(self):
         if self._h:
             self._lib.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """Several GPUs of one node behind the seam (rt_group_*): bands / strata ranges, assembled on devices[0]."""
+
+    def __init__(self, devices):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        capi.check(self._lib.rt_group_create(C.byref(self._h), arr, len(devices)), "rt_group_create")
+        self.params = None
+
+    def load(self, scene_file, params=None, desc=None):
+        p = params if params is not None else scene_file.params
+        capi.check(self._lib.rt_group_upload_scene(self._h, C.byref(desc if desc is not None else scene_file.desc)), "rt_group_upload_scene")
+        capi.check(self._lib.rt_group_set_camera(self._h, C.byref(scene_file.camera)), "rt_group_set_camera")
+        capi.check(self._lib.rt_group_set_params(self._h, C.byref(p)), "rt_group_set_params")
+        self.params = copy_params(p)
+
+    def render(self, want_hit=True):
+        H, W = self.params.height, self.params.width
+        rgb = np.empty((H, W, 3), dtype=np.float64)
+        hit = np.empty((H, W), dtype=np.int32) if want_hit else None
+        capi.check(self._lib.rt_group_render(self._h, rgb.ctypes.data, hit.ctypes.data if want_hit else None), "rt_group_render")
+        return rgb, hit
+
+    def render_u8(self, want_hit=False):
+        H, W = self.params.height, self.params.width
+        u8 = np.empty((H, W, 3), dtype=np.uint8)
+        hit = np.empty((H, W), dtype=np.int32) if want_hit else None
+        capi.check(self._lib.rt_group_render_u8(self._h, u8.ctypes.data, hit.ctypes.data if want_hit else None), "rt_group_render_u8")
+        return u8, hit
+
+    def stats(self):
+        st = capi.Stats()
+        capi.check(self._lib.rt_group_get_stats(self._h, C.byref(st)), "rt_group_get_stats")
+        return st
+
+    def close(self):
+        if self._h:
+            self._lib.rt_group_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

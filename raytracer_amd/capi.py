@@ -114,6 +114,15 @@ SYMBOLS = {
     "rt_set_workgroups": (C.c_int, [C.c_void_p, C.c_int32]),
     "rt_quantize_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rt_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
+    "rt_group_create": (C.c_int, [_P(C.c_void_p), _P(C.c_int), C.c_int]),
+    "rt_group_destroy": (None, [C.c_void_p]),
+    "rt_group_size": (C.c_int, [C.c_void_p]),
+    "rt_group_upload_scene": (C.c_int, [C.c_void_p, _P(SceneDesc)]),
+    "rt_group_set_camera": (C.c_int, [C.c_void_p, _P(Camera)]),
+    "rt_group_set_params": (C.c_int, [C.c_void_p, _P(Params)]),
+    "rt_group_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_group_render_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_group_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
     "rt_debug_trace_rays": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_math": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_optics": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -19,5 +19,5 @@ OBJS=""
 for tu in render_hip k_blockwave k_fused k_pathwave; do
   if [ -f variants/$NAME/$tu.o ]; then OBJS="$OBJS variants/$NAME/$tu.o"; else OBJS="$OBJS $tu.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o variants/libraytracer_amd_$NAME.so $OBJS host_scene.o fbvh_build.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o variants/libraytracer_amd_$NAME.so $OBJS rt_group.o host_scene.o fbvh_build.o
 echo variants/libraytracer_amd_$NAME.so

@@ -54,6 +54,8 @@ def read_p3(data):
 
 def main():
     assert os.path.exists(REF_BIN), "build oracle/_ref first: make -C oracle ref"
+    if "--pathtrace-only" in sys.argv:
+        return pathtrace_fixtures()
     outputs = {}
     for name in DETERMINISTIC:
         data = run_ref(os.path.join(REF, "scenes", name + ".json"))
@@ -85,8 +87,20 @@ def main():
     np.savez_compressed(os.path.join(OUT, "hit_ids_300x200.npz"), **maps)
 
     if "--pathtrace" in sys.argv:
-        for name, w, h, spp, ls, tm in [("pathtrace", 120, 80, 1024, 16, None), ("final", 120, 80, 256, 4, "uncharted2")]:
-            j = json.load(open(os.path.join(REF, "scenes", name + ".json")))
+        pathtrace_fixtures()
+
+
+def pathtrace_fixtures():
+    if True:  # (one block, kept at its indentation)
+        only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+        # final_textured_lens: BASELINE config 5's workload, derived from final.json by scripts/make_config5_scene.py
+        # (our file, under ROOT/scenes; the reference binary renders it from its own directory, where texture/ lies)
+        for name, w, h, spp, ls, tm in [("pathtrace", 120, 80, 1024, 16, None), ("final", 120, 80, 256, 4, "uncharted2"),
+                                        ("final_textured_lens", 120, 80, 1024, 16, "uncharted2")]:
+            if only and name not in only:
+                continue
+            src = os.path.join(REF, "scenes", name + ".json")
+            j = json.load(open(src if os.path.exists(src) else os.path.join(ROOT, "scenes", name + ".json")))
             j["camera"]["width"], j["camera"]["height"] = w, h
             j["lightsample"] = spp  # -> RayTracer::pixelSamples (the swap at RayTracer.cpp:138-139)
             j["pixelsample"] = ls   # -> RayTracer::lightSamples
