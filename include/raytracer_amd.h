@@ -251,6 +251,19 @@ int rt_render_u8(rt_context* ctx, uint8_t* rgb8, int32_t* hit_id);
  * Path-trace contexts are refused: their frames are sums until rt_pathtrace_resolve_device. */
 int rt_render_device_u8(rt_context* ctx, void* stream, uint8_t* rgb8_dev, double* rgb_dev, int32_t* hit_id_dev);
 
+/* rt_render_device_u8 WITHOUT any allocation.  No counterpart in the reference; it exists for callers that cannot
+ * call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * arguments, same frame (binary / phong modes; bit for bit).  All device workspace -- node store, hand-over records,
+ * parent lists, counters -- lies in a 256 MiB array that is part of the library's code object (every GPU the library
+ * runs on holds its own copy until the process ends); the first call of a (scene, params) setup makes the same
+ * attribute / occupancy queries as rt_render_device_u8 but no sizing frame, and nothing grows.  Limits: frames of at
+ * most ~3 x 10^5 pixels (about 640 x 480: three node records per pixel must fit; larger frames -> RT_ERR_LIMIT, use
+ * rt_render_device_u8); a frame whose ray forest outgrows the array sets the context's overflow flag, reported by
+ * the next call on the context or by rt_get_stats as for rt_render_device_u8.  Every call on a GPU shares that GPU's
+ * array, whichever context makes it: calls that overlap on one GPU (two streams, two contexts, two threads) race --
+ * serialize them.  The pipeline-selection variables of rt_create (RT_PIPELINE, RT_SPLIT_ROOTS) must be unset. */
+int rt_render_device_u8_static(rt_context* ctx, void* stream, uint8_t* rgb8_dev, double* rgb_dev, int32_t* hit_id_dev);
+
 /* Caps the grid of the persistent render kernels at n_workgroups (0 = as many as the chip holds, the
  * default; the environment variable RT_WORKGROUPS sets the initial value).  For callers that keep
  * several frames in flight on one GPU -- one context and one stream per frame, e.g. 4 contexts of 64

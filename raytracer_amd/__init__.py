@@ -113,6 +113,10 @@ class Renderer:
         """Whitted / binary frame as PPM bytes (and, optionally, the fp64 frame as well)."""
         capi.check(self._lib.rt_render_device_u8(self._h, stream, rgb8_ptr, rgb_ptr, hit_ptr), "rt_render_device_u8")
 
+    def render_device_u8_static(self, rgb8_ptr, rgb_ptr=None, hit_ptr=None, stream=None):
+        """rt_render_device_u8 out of the library's static workspace: no allocation (small frames only)."""
+        capi.check(self._lib.rt_render_device_u8_static(self._h, stream, rgb8_ptr, rgb_ptr, hit_ptr), "rt_render_device_u8_static")
+
     def accumulate_device(self, accum_ptr, stream=None):
         capi.check(self._lib.rt_pathtrace_accumulate_device(self._h, stream, accum_ptr),
                    "rt_pathtrace_accumulate_device")

@@ -111,6 +111,7 @@ SYMBOLS = {
     "rt_render_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_write_ppm_u8": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
     "rt_render_device_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_render_device_u8_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_set_workgroups": (C.c_int, [C.c_void_p, C.c_int32]),
     "rt_quantize_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rt_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),

@@ -239,6 +239,11 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         if (e_ != hipSuccess) return rt::set_error(RT_ERR_DEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Workspace of rt_render_device_u8_static (static_host.inc): device memory that exists from the moment the code
+// object is loaded on a GPU, so that the entry point needs no allocation.  Every GPU holds its own copy at its own
+// address.  In host code this name is only a handle for hipGetSymbolAddress -- never a device address.
+static __device__ __align__(256) unsigned char scratch[256ull << 20];
+
 struct rt_context {
     int device = 0;
     int n_cus = 0;
@@ -287,6 +292,8 @@ struct rt_context {
     unsigned long long generation = 1;  // bumped by upload / set_camera / set_params
     int n_point_lights = 0, n_area_lights = 0;
     DLight light0;  // host copy of the first light: pt_kernel takes it as a kernel argument
+    void* scratch_ptr = nullptr;                  // this device's copy of `scratch` (hipGetSymbolAddress at rt_create)
+    unsigned long long* last_counters = nullptr;  // the tallies the last render wrote (d_counters, or inside scratch)
     // wavefront node store
     double* d_wf_nodes = nullptr;
     int* d_wf_alive = nullptr;
@@ -359,10 +366,11 @@ int upload(T** dst, const std::vector<T>& src) {
 
 #include "wavefront_host.inc"
 #include "blockwave_host.inc"
+#include "static_host.inc"
 #include "gridwave_host.inc"
 
 int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_dev, bool accumulate_only,
-                  unsigned char* rgb8_dev = nullptr) {
+                  unsigned char* rgb8_dev = nullptr, bool static_workspace = false) {
     if (!c->have_scene || !c->have_camera || !c->have_params)
         return rt::set_error(RT_ERR_STATE, "render: scene, camera and params must be set first");
     const rt_params& p = c->params;
@@ -406,6 +414,8 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     A.ticket = c->d_ticket;
     A.counters = c->d_counters;
 
+    c->last_counters = c->d_counters;
+    if (static_workspace) return launch_fused_static(c, stream, A);
     c->last_was_wavefront = c->wavefront;
     if (c->wavefront) {
         c->scene_in_lds = c->sv.lds_bytes <= kMaxLdsImage ? 1 : 0;
@@ -548,6 +558,12 @@ int rt_create(rt_context** out, int device) {
     hipError_t h0 = hipHostMalloc((void**)&c->h_overflow, sizeof(unsigned), hipHostMallocMapped);
     hipError_t h1 = h0 == hipSuccess ? hipHostGetDevicePointer((void**)&c->d_overflow, c->h_overflow, 0) : h0;
     if (h1 == hipSuccess) *c->h_overflow = 0;
+    // this device's copy of the static workspace (the device is current: hipSetDevice above)
+    hipError_t sy = hipGetSymbolAddress(&c->scratch_ptr, HIP_SYMBOL(scratch));
+    if (sy != hipSuccess) {
+        rt_destroy(c);
+        return rt::set_error(RT_ERR_DEVICE, "rt_create: hipGetSymbolAddress(scratch) on device %d -> %s", device, hipGetErrorString(sy));
+    }
     if (a != hipSuccess || b != hipSuccess || s0 != hipSuccess || s1 != hipSuccess || h1 != hipSuccess) {
         rt_destroy(c);
         return rt::set_error(RT_ERR_DEVICE, "rt_create: device allocation failed");
@@ -913,6 +929,12 @@ int rt_render_device_u8(rt_context* c, void* stream, uint8_t* rgb8_dev, double* 
     return launch_render(c, (hipStream_t)stream, rgb_dev, hit_id_dev, false, rgb8_dev);
 }
 
+int rt_render_device_u8_static(rt_context* c, void* stream, uint8_t* rgb8_dev, double* rgb_dev, int32_t* hit_id_dev) {
+    if (!c || !rgb8_dev) return rt::set_error(RT_ERR_INVALID, "rt_render_device_u8_static: null argument");
+    if (!c->have_params) return rt::set_error(RT_ERR_STATE, "rt_render_device_u8_static: params not set");
+    return launch_render(c, (hipStream_t)stream, rgb_dev, hit_id_dev, false, rgb8_dev, true);
+}
+
 int rt_set_workgroups(rt_context* c, int32_t n_workgroups) {
     if (!c) return rt::set_error(RT_ERR_INVALID, "rt_set_workgroups: null context");
     if (n_workgroups < 0) return rt::set_error(RT_ERR_INVALID, "rt_set_workgroups: %d", n_workgroups);
@@ -1007,7 +1029,8 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
         out->kernel_ms = ms;
         std::vector<unsigned long long> rows((size_t)kCounterSlots * kCounterRow);
-        HIP_TRY(hipMemcpy(rows.data(), c->d_counters, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rows.data(), c->last_counters ? c->last_counters : c->d_counters, rows.size() * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost));
         unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t r = 0; r < (size_t)kCounterSlots; ++r)
             for (int k = 0; k < 5; ++k) cnt[k] += rows[r * kCounterRow + k];
