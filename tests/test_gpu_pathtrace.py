@@ -202,9 +202,12 @@ def test_different_seeds_differ_and_converge(renderer):
 @pytest.mark.parametrize("fixture", sorted(glob.glob(os.path.join(GOLDEN, "pt_ref_*.npy"))) or ["<none>"])
 def test_mse_against_reference_binary_render(renderer, fixture):
     """The committed images were rendered by the unmodified reference (oracle/_ref) with many
-    samples.  The GPU renders the same configuration with its own RNG; in the 8-bit output domain
-    the mean squared error must be what two independent Monte-Carlo estimates of one image give:
-    bound 4e-4 (i.e. RMS < 0.02 = 5/255), per-channel mean bias < 0.004."""
+    samples (1024 spp x 16 light samples for pathtrace.json and for config 5's final_textured_lens.json, 256 x 4 for
+    final.json).  The GPU renders the same configuration with its own RNG; in the 8-bit output domain the mean
+    squared error must be what two independent Monte-Carlo estimates of one image give, and the per-channel
+    mean difference must vanish.  Measured (3 seeds each, scripts/gpu_pt_stats.py): MSE 2.0e-6 .. 4.3e-6, bias
+    <= 2.5e-5.  Bounds: MSE < 2e-5, bias < 1e-4 -- a 1 % error in the direct light alone would shift the mean by
+    ~1e-3 (values ~0.7 after gamma)."""
     if fixture == "<none>":
         pytest.skip("no reference path-trace fixtures committed")
     base = os.path.basename(fixture)[len("pt_ref_"):-len(".npy")]
@@ -220,8 +223,8 @@ def test_mse_against_reference_binary_render(renderer, fixture):
     img = np.floor(255.999 * rgb[::-1]) / 255.0
     mse = np.mean((img - ref) ** 2)
     bias = np.abs((img - ref).mean(axis=(0, 1)))
-    assert mse < 4e-4, mse
-    assert bias.max() < 4e-3, bias
+    assert mse < 2e-5, mse
+    assert bias.max() < 1e-4, bias
 
 
 def test_sample_range_and_band_partitions_recombine(renderer):
