@@ -471,6 +471,16 @@ def test_cli_environment_overrides(renderer, tmp_path):
     assert got == lib(sf, P)
 
 
+def test_production_library_has_the_traversal_counters_compiled_out(renderer):
+    """The filter-BVH traversal's test counters cost 2-6 %; they belong to variants/libraytracer_amd_counts.so only
+    (a Makefile rule once built the production objects with -DRT_FBVH_COUNTS=1 unnoticed)."""
+    sf = scene_util.load("clutter_500", 150, 100)
+    renderer.load(sf)
+    renderer.render()
+    st = renderer.stats()
+    assert st.rays > 0 and st.box_tests == 0 and st.prim_tests == 0
+
+
 def test_render_u8_is_the_quantized_frame(renderer, tmp_path):
     """rt_render_u8 / rt_write_ppm_u8 == rt_render + rt_write_ppm, Whitted and path-traced."""
     for name, mode in (("clutter_500", None), ("pathtrace", rt.RT_MODE_PATHTRACE)):
