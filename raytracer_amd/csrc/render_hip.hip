@@ -696,6 +696,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sv.off_matidx = off;  off = align16(off + s->n_prims * 4);
     const int mat_bytes = align16(s->n_materials * (int)sizeof(DMaterial));
     sv.mat_staged = off + mat_bytes <= kMaxLdsImage ? 1 : 0;  // clutter_500: 500 materials = 48 KB do not fit
+    if (const char* e = std::getenv("RT_STAGE_MATERIALS")) if (std::atoi(e) == 0) sv.mat_staged = 0;  // A/B: records from the global copy
     if (sv.mat_staged) {
         sv.off_mat = off;
         off += mat_bytes;
