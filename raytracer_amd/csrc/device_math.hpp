@@ -311,5 +311,13 @@ RT_DEV double rng_u(const Rng& r, uint32_t node, uint32_t dim) {
     uint64_t bits = (dim & 1) ? (((uint64_t)o[3] << 32) | o[2]) : (((uint64_t)o[1] << 32) | o[0]);
     return (double)(bits >> 11) * 0x1.0p-53;
 }
+// the two uniforms of one counter block: rng_u(r, node, 2 * block) and rng_u(r, node, 2 * block + 1) from ONE Philox
+// call (written as two rng_u calls the compiler cannot see that dim >> 1 is the same block when dim is computed)
+RT_DEV void rng_u2(const Rng& r, uint32_t node, uint32_t block, double& u0, double& u1) {
+    uint32_t o[4];
+    philox4x32_10(r.pixel, r.sample, node, block, r.k0, r.k1, o);
+    u0 = (double)((((uint64_t)o[1] << 32) | o[0]) >> 11) * 0x1.0p-53;
+    u1 = (double)((((uint64_t)o[3] << 32) | o[2]) >> 11) * 0x1.0p-53;
+}
 
 }  // namespace rtd

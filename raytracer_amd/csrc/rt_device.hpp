@@ -1006,9 +1006,10 @@ RT_DEV D3 hemisphere(D3 n, double r1, double r2) {  // randomInHemisphere, RayTr
 template <bool kShared = false>  // kShared: ldir / distance through div3 (same bits)
 RT_DEV void area_sample(const RenderArgs& A, const DLight& Lt, const Rng& rng, unsigned node, int li, int si, D3 point,
                         D3& ldir, double& distance, double& pdf) {
-    unsigned dim = DIM_LIGHT0 + 2u * (unsigned)(li * A.light_samples + si);
-    double su = (rng_u(rng, node, dim) - 0.5) * Lt.width;
-    double sv = (rng_u(rng, node, dim + 1) - 0.5) * Lt.height;
+    double u0, u1;  // dimensions DIM_LIGHT0 + 2 m and + 2 m + 1 of sample m = li * light_samples + si: one counter block
+    rng_u2(rng, node, DIM_LIGHT0 / 2 + (unsigned)(li * A.light_samples + si), u0, u1);
+    double su = (u0 - 0.5) * Lt.width;
+    double sv = (u1 - 0.5) * Lt.height;
     D3 sp = ld3(Lt.position) + ld3(Lt.u) * su + ld3(Lt.v) * sv;
     ldir = sp - point;
     distance = length(ldir);
