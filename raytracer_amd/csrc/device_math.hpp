@@ -26,7 +26,23 @@ RT_DEV D3 operator-(D3 a, double s) { return D3{a.x - s, a.y - s, a.z - s}; }
 RT_DEV D3 operator-(D3 a) { return D3{-a.x, -a.y, -a.z}; }
 RT_DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // Vector3.cpp:48-50
 RT_DEV D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-RT_DEV double length(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // Vector3.cpp:72-75
+// sqrt() of the device library is rsq, a Goldschmidt step and two correction steps, wrapped in a rescaling for
+// arguments below 2^-767 and a pass-through for 0 / inf (6 of its 17 instructions).  For arguments in
+// [2^-766, 2^1022) this is the same sequence without the wrapping, hence the same (correctly rounded) bits; others
+// take the library call.  tests/test_gpu_rays.py::test_division_and_sqrt_are_correctly_rounded covers it.
+RT_DEV double sqrt_windowed(double x) {
+    if ((unsigned)__double2hiint(x) - 0x10100000u >= 0x6FD00000u) return sqrt(x);  // also negative, NaN
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+RT_DEV double length(D3 a) { return sqrt_windowed(a.x * a.x + a.y * a.y + a.z * a.z); }  // Vector3.cpp:72-75
 RT_DEV double refine_rcp(double d);
 RT_DEV double div_shared(double a, double d, double r);
 // Vector3.cpp:78-81: three true divisions by the same length.  hipcc expands each into 11-12 instructions; when

@@ -223,6 +223,7 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 10: r = normalize(mk(y, 0.75 * y, x)).z; break;
         case 11: r = div3(mk(x, 0.75 * x, -1.5 * x), y).x; break;  // D3 / double through one shared reciprocal when exact
         case 12: r = div3(mk(0.75 * x, -1.5 * x, x), y).z; break;
+        case 13: r = sqrt_windowed(x); break;  // the library's sqrt without its rescaling wrapper when that is the identity
         default: r = 0.0;
     }
     out[k] = r;

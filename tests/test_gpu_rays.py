@@ -33,6 +33,31 @@ def test_division_and_sqrt_are_correctly_rounded(renderer):
     assert np.array_equal(renderer.math(1, x), np.sqrt(x))
 
 
+def test_windowed_sqrt_is_the_library_sqrt(renderer):
+    """device_math.hpp sqrt_windowed (op 13, behind every length()): the device library's sequence without its
+    rescaling wrapper inside [2^-766, 2^1022), the library call outside -- correctly rounded either way, window edges,
+    perfect squares, mantissas next to 1 and 4, zeros, denormals, inf and NaN included."""
+    rng = np.random.default_rng(17)
+    n = 6_000_000
+    with np.errstate(over="ignore"):
+        x = np.exp2(rng.uniform(-1074, 1024, n)) * rng.uniform(1, 2, n)  # a few overflow to inf: also a case
+    m = 200_000
+    near = np.frombuffer((np.uint64(0x3FF0000000000000) + rng.integers(-6, 7, m).astype(np.int64).astype(np.uint64)).tobytes(),
+                         dtype=np.float64)
+    x[:m] = near * np.exp2(rng.integers(-800, 1023, m).astype(np.float64))          # just around powers of two
+    k = rng.integers(1, 2 ** 26, m).astype(np.float64)
+    x[m:2 * m] = k * k * np.exp2(2.0 * rng.integers(-300, 300, m))                  # perfect squares
+    edge = np.array([0x10100000, 0x100FFFFF, 0x7FE00000, 0x7FDFFFFF, 0x7FEFFFFF, 0x00100000, 0x000FFFFF], dtype=np.uint64)
+    x[2 * m:2 * m + 7] = np.frombuffer(((edge << np.uint64(32)) | np.uint64(0xFFFFFFFF)).tobytes(), dtype=np.float64)
+    x[2 * m + 7:2 * m + 14] = np.frombuffer((edge << np.uint64(32)).tobytes(), dtype=np.float64)
+    x[2 * m + 14:2 * m + 20] = [0.0, -0.0, np.inf, np.nan, 5e-324, -1.0]
+    with np.errstate(all="ignore"):
+        expect = np.sqrt(x)
+    got = renderer.math(13, x)
+    assert np.array_equal(got, expect, equal_nan=True)
+    assert np.array_equal(np.signbit(got[~np.isnan(expect)]), np.signbit(expect[~np.isnan(expect)]))
+
+
 def test_shared_reciprocal_division_is_exact(renderer):
     """device_math.hpp div_shared: op 8 evaluates a / d through refine_rcp(d) + 3 instructions; inside
     the window ray_regular() guarantees it must equal the IEEE quotient bit for bit, including
