@@ -42,6 +42,20 @@ RT_DEV double sqrt_windowed(double x) {
     d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
+// sqrt(x) and 1 / sqrt(x) from ONE reciprocal-square-root estimate: the library sequence's Goldschmidt step refines
+// both, one correction step on the root (within an ulp of sqrt(x); the reciprocal within two).  For callers that are
+// held to a tolerance, not to the reference's bits (pt_kernel's regrouped light sample).  x = 0, negative or NaN
+// gives NaNs, which those callers' guards turn into a zero contribution.
+RT_DEV void sqrt_and_rsqrt(double x, double& root, double& inv) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    root = __builtin_fma(d, h, g);
+    inv = h + h;
+}
 RT_DEV double length(D3 a) { return sqrt_windowed(a.x * a.x + a.y * a.y + a.z * a.z); }  // Vector3.cpp:72-75
 RT_DEV double refine_rcp(double d);
 RT_DEV double div_shared(double a, double d, double r);

@@ -278,6 +278,7 @@ struct rt_context {
     int traversal = 3;           // 0 ref, 1 walk (same visits as the reference), 2 cull (+ any-hit shadows), 3 filter BVH
     bool wavefront = true;       // RT_PIPELINE=mega selects the persistent per-pixel kernel
     bool level_kernels = false;  // RT_PIPELINE=levels: one kernel per phase and depth instead of one per frame
+    bool pt_exact = false;       // RT_PT_EXACT=1: pt_kernel evaluates an area-light sample in the reference's operation order (no regrouping)
     bool pt_generic = false;     // RT_PT_GENERIC=1: path trace with bw_kernel<1> (any lights / sample counts) even where pt_kernel applies
     int fused = -1;              // one pass per level (fused_kernels.inc): -1 = Whitted yes, path trace no; RT_PIPELINE=fused / block force it
     unsigned* d_bw_info = nullptr;
@@ -547,6 +548,7 @@ int rt_create(rt_context** out, int device) {
     c->gridwave = pipe && std::strcmp(pipe, "grid") == 0;
     if (const char* e = std::getenv("RT_SPLIT_ROOTS")) c->split_roots = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_PT_GENERIC")) c->pt_generic = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_PT_EXACT")) c->pt_exact = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_WF_DEBUG_CAP")) c->debug_cap = std::max(0ll, std::atoll(e));
     if (const char* e = std::getenv("RT_WF_DEBUG_SHRINK")) c->debug_shrink = std::atof(e);
     c->n_cus = prop.multiProcessorCount;

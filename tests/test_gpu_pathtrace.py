@@ -74,6 +74,28 @@ def test_general_kernel_equals_the_row_kernel():
         g.close(); r.close()
 
 
+def test_regrouped_light_sample_equals_the_reference_order():
+    """pt_kernel regroups an area-light sample's arithmetic (one reciprocal square root for distance and direction, the
+    pdf folded into one weight, no second normalize of the unit direction); RT_PT_EXACT=1 keeps the reference's operation
+    order.  Same rays; radiance within a few ulp per sample."""
+    from tests.conftest import _make
+    e = _make({"RT_PT_EXACT": "1"})
+    r = _make({})
+    try:
+        for name, spp, ls in (("pathtrace", 16, 16), ("final", 4, 8)):
+            sf = scene_util.load(name, 150, 100)
+            P = sf.params
+            P.pixel_samples, P.light_samples = spp, ls
+            e.load(sf, P); r.load(sf, P)
+            a, _ = e.render(want_hit=False)
+            b, _ = r.render(want_hit=False)
+            assert e.stats().rays == r.stats().rays
+            assert np.abs(a - b).max() < 1e-12
+            assert not np.array_equal(a, b)   # (the knob does something)
+    finally:
+        e.close(); r.close()
+
+
 def test_two_lights_take_the_general_kernel(renderer):
     """A point light beside the area light (S = 1 + 4 shadow rays per hit): not pt_kernel's case."""
     sf = scene_util.load("pathtrace", 90, 60)
