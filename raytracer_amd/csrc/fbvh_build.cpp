@@ -323,8 +323,13 @@ void build_filter_bvh(const rt_scene_desc* s, const FlatBVH* ref_bvh, FilterBVH&
         for (int i = 0; i < n; ++i) key_of[i] = -i;  // linear scan: the first object wins
     }
     out.leaf_prim.resize((size_t)n * 4);
+    out.leaf_box.resize((size_t)n * 6);
     for (int k = 0; k < n; ++k) {
         int p = b.order[k];
+        for (int a = 0; a < 3; ++a) {
+            out.leaf_box[(size_t)k * 6 + a] = round_down(b.pbox[p].lo[a]);
+            out.leaf_box[(size_t)k * 6 + 3 + a] = round_up(b.pbox[p].hi[a]);
+        }
         out.leaf_prim[(size_t)k * 4 + 0] = p;
         out.leaf_prim[(size_t)k * 4 + 1] = gate_of[p];
         out.leaf_prim[(size_t)k * 4 + 2] = key_of[p];

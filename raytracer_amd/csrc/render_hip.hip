@@ -279,6 +279,7 @@ struct rt_context {
     bool wavefront = true;       // RT_PIPELINE=mega selects the persistent per-pixel kernel
     bool level_kernels = false;  // RT_PIPELINE=levels: one kernel per phase and depth instead of one per frame
     bool pt_exact = false;       // RT_PT_EXACT=1: pt_kernel evaluates an area-light sample in the reference's operation order (no regrouping)
+    int pt_classes = 2;          // RT_PT_CLASSES=0: pt_kernel treats every hit as general; 1: dark hits only; 2: dark and clear-shaft hits
     bool pt_generic = false;     // RT_PT_GENERIC=1: path trace with bw_kernel<1> (any lights / sample counts) even where pt_kernel applies
     int fused = -1;              // one pass per level (fused_kernels.inc): -1 = Whitted yes, path trace no; RT_PIPELINE=fused / block force it
     unsigned* d_bw_info = nullptr;
@@ -549,6 +550,7 @@ int rt_create(rt_context** out, int device) {
     if (const char* e = std::getenv("RT_SPLIT_ROOTS")) c->split_roots = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_PT_GENERIC")) c->pt_generic = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_PT_EXACT")) c->pt_exact = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_PT_CLASSES")) c->pt_classes = std::min(2, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("RT_WF_DEBUG_CAP")) c->debug_cap = std::max(0ll, std::atoll(e));
     if (const char* e = std::getenv("RT_WF_DEBUG_SHRINK")) c->debug_shrink = std::atof(e);
     c->n_cus = prop.multiProcessorCount;
@@ -678,7 +680,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     long long total_bytes = 0;
     {
         const long long np = s->n_prims;
-        total_bytes += fb.ok ? (long long)fb.n_nodes * kFNodeBytes + np * kLeafBytes : 0;
+        total_bytes += fb.ok ? (long long)fb.n_nodes * kFNodeBytes + np * (kLeafBytes + 32) : 0;
         total_bytes += ((long long)sph.size() + (long long)tri.size() + (long long)cyl.size()) * 8;
         total_bytes += np * 4 * 3 + (long long)s->n_materials * (long long)sizeof(DMaterial);
         total_bytes += (long long)sv.n_nodes * kNodeBytes + 16 * 16;
@@ -711,6 +713,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
     sv.off_nodes = off; off = align16(off + sv.n_nodes * kNodeBytes);
     sv.off_ref = off;   off = align16(off + s->n_prims * 4);
+    sv.off_leafbox = off;
+    if (fb.ok) off = align16(off + s->n_prims * 32);  // read by pt_classify only, from the global copy
     sv.image_bytes = std::max(off, 16);
     if (std::getenv("RT_WF_DEBUG"))
         std::fprintf(stderr, "[scene] %d prims, %d filter nodes (%d B), leaf records %d B, primitives %d B, materials %d B (%s), staged %d B of %d B\n",
@@ -786,6 +790,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             unsigned char* dst = image.data() + sv.off_leafprim + (size_t)k * kLeafBytes;
             std::memcpy(dst, rec, 16);
             if (gate >= 0) std::memcpy(dst + 16, &bvh.box[(size_t)gate * 6], 48);
+            const float* lb = &fb.leaf_box[(size_t)k * 6];  // lo xyz, hi xyz -> the filter nodes' (lo, hi) pairs per axis
+            const float pairs[8] = {lb[0], lb[3], lb[1], lb[4], lb[2], lb[5], 0.f, 0.f};
+            std::memcpy(image.data() + sv.off_leafbox + (size_t)k * 32, pairs, 32);
         }
     }
 

@@ -93,6 +93,7 @@ struct SceneView {
     int regular;  // every coordinate is 0 or within [2^-300, 2^300]: shared-reciprocal division is exact
     int fbvh_ok, n_fnodes;                       // filter BVH present (fbvh_build.cpp)
     int off_fnodes, off_leafprim;                // 96 B nodes (box, leaf range, [octant] int2 links), 64 B leaf records
+    int off_leafbox;                             // 32 B per leaf record: the primitive's own enlarged fp32 box, laid out like a node's (global copy only; pt_classify)
     double scene_scale;
     const unsigned char* image;  // global copy of the image
     const DMaterial* materials;

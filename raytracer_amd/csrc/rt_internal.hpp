@@ -44,6 +44,7 @@ struct FilterBVH {
     std::vector<int32_t> leaf_count;   // [n] number of records (0 for inner nodes)
     std::vector<int32_t> links;        // [n][8 octants][2]: next node when the box passes / fails; -1 = done
     std::vector<int32_t> leaf_prim;    // [n_prims][4]: primitive ID, gate = reference node index or -1, tie key, 0
+    std::vector<float> leaf_box;       // [n_prims][6], in leaf_prim's order: the primitive's own enlarged box, lo xyz, hi xyz, rounded outward
 };
 void build_filter_bvh(const rt_scene_desc* scene, const FlatBVH* ref_bvh, FilterBVH& out);
 

@@ -96,6 +96,57 @@ def test_regrouped_light_sample_equals_the_reference_order():
         e.close(); r.close()
 
 
+def test_hit_classes_change_no_bit():
+    """pt_kernel sorts a level's hits into dark (the whole light behind the surface or the hit behind the light: direct
+    light exactly 0), clear (the shaft from the hit to the light misses every other primitive's enlarged box: no any-hit
+    walks) and general before its light phase.  Both shortcuts are exact: RT_PT_CLASSES=0 (every hit general) and
+    RT_PT_CLASSES=1 (dark only) must give the same bits and the same ray count as the default, on the shipped scenes
+    (open, closed box, textured, thin lens) and on random soups of all three primitive types -- glass and mirrors among
+    them -- under randomly placed, tilted, large and small area lights."""
+    from tests.conftest import _make
+    rs = [_make({"RT_PT_CLASSES": "0"}), _make({"RT_PT_CLASSES": "1"}), _make({})]
+    try:
+        cases = []
+        for name, spp, ls in (("pathtrace", 4, 16), ("final", 4, 8), ("final_textured_lens", 4, 4), ("lens_sampling", 4, 2),
+                              ("indirect_light", 4, 4), ("brdf", 4, 4)):
+            sf = scene_util.load(name, 150, 100)
+            P = sf.params
+            P.mode = rt.RT_MODE_PATHTRACE
+            P.pixel_samples, P.light_samples = spp, ls
+            cases.append((name, sf.desc, sf.camera, P, sf))
+        rng = np.random.default_rng(77)
+        mats = [scene_util.default_material(), scene_util.default_material(reflective=1, reflectivity=0.8),
+                scene_util.default_material(refractive=1, ior=1.5), scene_util.default_material(diffuse=(0.2, 0.9, 0.3), exp=5)]
+        for k in range(10):
+            n_sph, n_tri, n_cyl = [(6, 6, 4), (40, 30, 20), (1, 0, 0), (0, 2, 1), (150, 100, 50)][k % 5]
+            types, geom = scene_util.random_prims(rng, n_sph, n_tri, n_cyl, extent=3.0)
+            nrm = rng.standard_normal(3)
+            nrm /= np.linalg.norm(nrm)
+            u = np.cross(nrm, rng.standard_normal(3))
+            u /= np.linalg.norm(u)
+            v = np.cross(nrm, u)
+            size = [0.02, 0.5, 2.0, 6.0][k % 4]          # a thin shaft ... a light larger than the scene
+            pos = rng.uniform(-3, 3, 3) if k % 3 else rng.uniform(-12, 12, 3)  # inside the soup / outside it
+            light = scene_util.area_light(pos, nrm, u, v, size, size * rng.uniform(0.3, 1.0))
+            syn = scene_util.SyntheticScene(types, geom, materials=mats, lights=[light], use_bvh=k % 2,
+                                            prim_material=rng.integers(0, len(mats), len(types)))
+            cam = scene_util.look_at(rng.uniform(-6, 6, 3), (0, 0, 0), aspect=1.5)
+            P = scene_util.make_params(120, 80, mode=rt.RT_MODE_PATHTRACE, max_depth=6, pixel_samples=4, light_samples=[4, 16, 1, 8][k % 4], seed=k)
+            cases.append((f"soup{k}", syn.desc, cam, P, syn))
+        for name, desc, cam, P, keep in cases:
+            out = []
+            for r in rs:
+                r.upload(desc); r.set_camera(cam); r.set_params(P)
+                rgb, _ = r.render(want_hit=False)
+                out.append((rgb, r.stats().rays))
+            for rgb, rays in out[:2]:
+                assert rays == out[2][1], name
+                assert np.array_equal(rgb, out[2][0]), name
+    finally:
+        for r in rs:
+            r.close()
+
+
 def test_two_lights_take_the_general_kernel(renderer):
     """A point light beside the area light (S = 1 + 4 shadow rays per hit): not pt_kernel's case."""
     sf = scene_util.load("pathtrace", 90, 60)
