@@ -73,7 +73,7 @@ def executed_counts_child(workload, spp):
     r.render_u8() if workload != "pathtrace_1080p" else r.render(want_hit=False)
     st = r.stats()
     print(json.dumps({"rays": st.rays, "box": st.box_tests, "sphere": st.sphere_tests, "tri": st.triangle_tests,
-                      "cyl": st.cylinder_tests}))
+                      "cyl": st.cylinder_tests, "walks": st.rays_traversed}))
 
 
 def executed_counts(workload, spp):
@@ -93,7 +93,12 @@ def executed_counts(workload, spp):
         return None
     rays = max(c["rays"], 1)
     prim = c["sphere"] + c["tri"] + c["cyl"]
-    return {"executed_box_tests_per_ray": c["box"] / rays, "executed_prim_tests_per_ray": prim / rays,
+    return {"rays_traversed_per_ray": c.get("walks", 0) / rays,
+            "rays_traversed_note": "every ray of the reference (one Scene::intersect call) is counted; a ray whose answer cannot "
+                                   "reach the image is not walked: shadow rays of a Whitted hit that refracts (RayTracer.cpp:798 "
+                                   "replaces its local colour), of a path-traced hit that faces away from the whole light or "
+                                   "whose shaft to the light is empty",
+            "executed_box_tests_per_ray": c["box"] / rays, "executed_prim_tests_per_ray": prim / rays,
             "executed_ops_per_ray": (OPS_BOX * c["box"] + OPS_SPHERE * c["sphere"] + OPS_TRI * c["tri"] + OPS_CYL * c["cyl"]) / rays,
             "executed_note": "filter-BVH traversal: box tests = fp32 node tests (21 instructions each, priced like an fp64 box "
                              "test here) + fp64 gate tests; from one untimed frame of the -DRT_FBVH_COUNTS=1 build"}

@@ -162,6 +162,11 @@ typedef struct rt_stats {
     double upload_ms;      /* last scene upload (host flatten + H2D)                           */
     int32_t n_bvh_nodes;   /* flattened BVH nodes (0 in linear mode)                           */
     int32_t scene_in_lds;  /* 1 if the scene image was staged in LDS                           */
+    uint64_t rays_traversed; /* of `rays`, those whose traversal was started: a ray whose answer cannot
+                              * reach the image (shadow rays of a hit that refracts, RayTracer.cpp:798;
+                              * of a path-traced hit the light cannot reach or see) is counted in `rays`
+                              * but not walked.  Counted like box_tests: 0 for the default traversal
+                              * unless built with -DRT_FBVH_COUNTS=1                              */
 } rt_stats;
 
 typedef struct rt_context rt_context;       /* device-side renderer, one per GPU             */

@@ -80,6 +80,7 @@ class Stats(C.Structure):
         ("sphere_tests", C.c_uint64), ("triangle_tests", C.c_uint64), ("cylinder_tests", C.c_uint64),
         ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
         ("n_bvh_nodes", C.c_int32), ("scene_in_lds", C.c_int32),
+        ("rays_traversed", C.c_uint64),
     ]
 
 

@@ -1044,8 +1044,9 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
                           hipMemcpyDeviceToHost));
         unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t r = 0; r < (size_t)kCounterSlots; ++r)
-            for (int k = 0; k < 5; ++k) cnt[k] += rows[r * kCounterRow + k];
+            for (int k = 0; k < 6; ++k) cnt[k] += rows[r * kCounterRow + k];
         out->rays = cnt[0];
+        out->rays_traversed = cnt[5];
         out->box_tests = cnt[1];
         out->sphere_tests = cnt[2];
         out->triangle_tests = cnt[3];

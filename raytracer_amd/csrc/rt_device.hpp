@@ -139,6 +139,7 @@ struct HitT {
 
 struct Tally {
     unsigned rays, box, sph, tri, cyl;
+    unsigned walks;  // traversals actually started (trace_ray): below `rays` where a ray's answer cannot reach the image and is not computed
 };
 
 // Adds a wave's tallies to the row this wave owns (rows are per (block, wave); kernels on one
@@ -147,19 +148,19 @@ struct Tally {
 // `overwrite`: the first kernel of a frame stores instead of adding, which spares the host a 2 MB memset per
 // frame (a fill kernel that has to wait for a free CU when several frames are in flight).
 RT_DEV void flush_tally(const Tally& tally, unsigned long long* counters, bool overwrite = false) {
-    unsigned long long c[5] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl};
+    unsigned long long c[6] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl, tally.walks};
     for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 5; ++k) c[k] += __shfl_down(c[k], off);
+        for (int k = 0; k < 6; ++k) c[k] += __shfl_down(c[k], off);
     if ((threadIdx.x & 63) == 0) {
         unsigned row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (row < (unsigned)kCounterSlots) {
             unsigned long long* r = counters + (size_t)row * kCounterRow;
             if (overwrite)
-                for (int k = 0; k < 5; ++k) r[k] = c[k];
+                for (int k = 0; k < 6; ++k) r[k] = c[k];
             else
-                for (int k = 0; k < 5; ++k) r[k] += c[k];
+                for (int k = 0; k < 6; ++k) r[k] += c[k];
         } else {
-            for (int k = 0; k < 5; ++k)
+            for (int k = 0; k < 6; ++k)
                 if (c[k]) atomicAdd(&counters[k], c[k]);
         }
     }
@@ -503,6 +504,7 @@ RT_DEV HitT closest_hit_fbvh(P img, const SceneView& sv, D3 o, D3 d, Tally& tall
 // kTrav: 1 = visit-for-visit walk of the reference tree, 2 = + culling / any-hit, 3 = filter BVH
 template <int kTrav, bool kAny, typename P>
 RT_DEV HitT trace_ray(P img, const SceneView& sv, D3 o, D3 d, Tally& tally, double t_limit = 0.0) {
+    if (kTrav != 3 || RT_FBVH_COUNTS) ++tally.walks;  // (like the test counters: compiled out of the production traversal)
     if (kTrav == 3) return closest_hit_fbvh<kAny>(img, sv, o, d, tally, t_limit);
     if (kTrav == 2) return closest_hit_fast<true, kAny>(img, sv, o, d, tally, t_limit);
     HitT h = closest_hit_fast<false, false>(img, sv, o, d, tally);

@@ -325,6 +325,7 @@ int rt_group_get_stats(rt_group* g, rt_stats* out) {
         rt_stats st;
         RT_TRY(rt_get_stats(me.ctx, &st));
         out->rays += st.rays;
+        out->rays_traversed += st.rays_traversed;
         out->box_tests += st.box_tests;
         out->prim_tests += st.prim_tests;
         out->sphere_tests += st.sphere_tests;

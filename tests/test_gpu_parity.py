@@ -545,3 +545,18 @@ def test_frame_pipeline_with_frames_in_flight_on_streams(renderer):
     finally:
         for r in ctxs:
             r.close()
+
+
+def test_counting_traversal_walks_every_ray(renderer_walk, renderer):
+    """A ray whose answer cannot reach the image (the shadow rays of a hit that refracts: RayTracer.cpp:798 replaces its
+    local colour) is counted but not walked by the production traversal; the walk traversal, which makes the reference's
+    own test counts, starts a traversal for every ray it counts, and both give the same frame."""
+    sf = scene_util.load("mirror_glass_cylinder", 300, 200)
+    out = []
+    for r in (renderer_walk, renderer):
+        r.load(sf)
+        rgb, hit = r.render()
+        out.append((rgb, hit, r.stats()))
+    assert out[0][2].rays_traversed == out[0][2].rays == out[1][2].rays
+    assert out[1][2].rays_traversed == 0  # (compiled out of the production library, like its test counters)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
