@@ -45,6 +45,10 @@ constexpr int kTraceBlock = RT_TRACE_BLOCK;  // threads per workgroup of the fra
 #ifndef RT_FUSED_BLOCK
 #define RT_FUSED_BLOCK 768
 #endif
+#ifndef RT_FW_BLOCK
+#define RT_FW_BLOCK RT_FUSED_BLOCK
+#endif
+constexpr int kFwBlock = RT_FW_BLOCK;  // fw_kernel's own workgroup size (fw_roots_kernel: kFusedBlock)
 constexpr int kFusedBlock = RT_FUSED_BLOCK;  // fused Whitted kernels: 168 VGPRs per lane (428 B of scratch instead of 604 B) beat a fourth wave per SIMD
 constexpr int kMaxLdsImage = 150 * 1024;
 constexpr int kNF = 26;              // doubles per frame
