@@ -127,6 +127,11 @@ def test_hit_classes_change_no_bit():
             v = np.cross(nrm, u)
             size = [0.02, 0.5, 2.0, 6.0][k % 4]          # a thin shaft ... a light larger than the scene
             pos = rng.uniform(-3, 3, 3) if k % 3 else rng.uniform(-12, 12, 3)  # inside the soup / outside it
+            if k % 2:  # a `normal` that is not perpendicular to u and v, and u, v that are not perpendicular to each other
+                nrm = nrm + 0.7 * u
+                nrm /= np.linalg.norm(nrm)
+                v = v + 0.5 * u
+                v /= np.linalg.norm(v)
             light = scene_util.area_light(pos, nrm, u, v, size, size * rng.uniform(0.3, 1.0))
             syn = scene_util.SyntheticScene(types, geom, materials=mats, lights=[light], use_bvh=k % 2,
                                             prim_material=rng.integers(0, len(mats), len(types)))
