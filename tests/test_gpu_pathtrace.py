@@ -196,6 +196,39 @@ def test_headline_configuration_at_full_size(renderer):
     assert 0.3 < rgb.mean() < 0.9   # sky-lit scene, gamma applied
 
 
+def test_config5_workload_at_full_size(renderer):
+    """BASELINE config 5's workload at its own size: final_textured_lens.json (final.json + textures + thin lens) at
+    3840x2160 with pixelSamples 4096 (64x64 strata), lightSamples 16.  One stratum of the 4K frame against the oracle
+    (same rays exactly; radiance sums to 1e-9 but for the few pixels where an atan2 / acos last bit picks the neighbouring
+    texel), then eight strata: finite, non-negative, and as many rays as one stratum predicts."""
+    import torch
+    W, H = 3840, 2160
+    sf = scene_util.load("final_textured_lens", W, H, tonemap="uncharted2")
+    P = sf.params
+    P.pixel_samples, P.light_samples = 4096, 16
+    stream = torch.cuda.current_stream().cuda_stream
+    acc = torch.empty(H * W * 3, dtype=torch.float64, device="cuda")
+    Q = rt.copy_params(P)
+    Q.sample_begin, Q.sample_end = 2077, 2078
+    renderer.load(sf, Q)
+    renderer.accumulate_device(acc.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    st = renderer.stats()
+    _, _, cnt, oacc = oracle_lib.render(sf.desc, sf.camera, Q, want_hit=False, want_accum=True)
+    got = acc.cpu().numpy().reshape(H, W, 3)
+    outliers = (np.abs(got - oacc).max(axis=2) > 1e-9).mean()
+    assert outliers <= 2e-3
+    assert abs(st.rays - cnt["rays"]) <= (0 if outliers == 0 else 1e-3 * cnt["rays"])
+    one_stratum = st.rays
+    Q.sample_begin, Q.sample_end = 0, 8
+    renderer.set_params(Q)
+    renderer.accumulate_device(acc.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    got = acc.cpu().numpy()
+    assert np.isfinite(got).all() and got.min() >= 0.0
+    assert abs(renderer.stats().rays / 8 - one_stratum) < 0.01 * one_stratum
+
+
 @pytest.mark.parametrize("which", ["levels", "mega", "fused_whole"])
 def test_other_pipelines_path_trace_the_same_image(request, which):
     r = request.getfixturevalue("renderer_" + which)
