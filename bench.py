@@ -104,6 +104,15 @@ def executed_counts(workload, spp):
                              "test here) + fp64 gate tests; from one untimed frame of the -DRT_FBVH_COUNTS=1 build"}
 
 
+def add_executed_rates(line, roof, rays_per_step, ms_per_step):
+    """The conservative companions of `value` and `roofline.achieved`: only the rays whose traversal was started, and
+    only the box / primitive tests the production traversal executed (priced like the reference's)."""
+    per_s = rays_per_step / (ms_per_step * 1e-3)
+    line["mrays_per_s_traversed_only"] = per_s * roof["rays_traversed_per_ray"] / 1e6
+    roof["achieved_executed"] = roof["executed_ops_per_ray"] * per_s / line["n_gpus"] / 1e12
+    roof["frac_executed"] = roof["achieved_executed"] / FP64_VALU_PEAK_TOPS
+
+
 def quoted_profile(name):
     """Numbers that cannot be measured inside this process (rocprofv3 PMC passes), quoted from the committed
     profile with its source; None if the file is absent."""
@@ -439,7 +448,9 @@ def main():
     if do_w:
         line, setup = b.whitted()
         if rank == 0:
-            if exe_w: line["roofline"].update(exe_w)
+            if exe_w:
+                line["roofline"].update(exe_w)
+                add_executed_rates(line, line["roofline"], line["config"]["rays_per_step"], line["ms_per_step"])
             q = quoted_profile("r02_clutter_500_pmc.json")
             if q and world == 1:
                 line["roofline"]["traffic"] = q.get("hbm_bytes_per_frame")
@@ -451,7 +462,9 @@ def main():
     if do_p:
         block, setup = b.pathtrace()
         if rank == 0:
-            if exe_p: block["roofline"].update(exe_p)
+            if exe_p:
+                block["roofline"].update(exe_p)
+                add_executed_rates(block, block["roofline"], block["config"]["rays_per_step"], block["ms_per_step"])
             q = quoted_profile("r02_pathtrace_pmc.json")
             if q and world == 1:
                 block["roofline"]["traffic"] = q.get("hbm_bytes_per_launch")
