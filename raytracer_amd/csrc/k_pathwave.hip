@@ -1,4 +1,5 @@
 // k_pathwave.hip -- instantiates the production path-trace kernel pt_kernel (pathwave_kernels.inc).
+#define RT_TEXTURE_CALL 1  // the textured colour as a real call (rt_device.hpp: textured_colour)
 #include "rt_device.hpp"
 
 namespace rt {

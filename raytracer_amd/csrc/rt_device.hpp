@@ -624,12 +624,29 @@ RT_DEV D3 texture_color(const SceneView& sv, const DMaterial& m, double u, doubl
     return mk(px[0] / 255.0, px[1] / 255.0, px[2] / 255.0);
 }
 
+#ifndef RT_TEXTURE_CALL
+#define RT_TEXTURE_CALL 0
+#endif
+// The textured case as a real call (k_pathwave.hip: pt_kernel): getUV's atan2 / acos bring ~40 polynomial coefficients
+// that the compiler otherwise hoists out of the kernel's loops into vector registers and spills (one scratch reload per
+// coefficient and use, each waited for: final_textured_lens.json 40.7 -> 38.8 ms per 16 strata at 1080p; 41 instead of
+// 99 spilled dwords).  Not for the fused Whitted kernels: 36 instead of 81 spilled dwords there too, but clutter_500
+// renders 4 % slower with a call in the kernel (28.3 against 29.5 Grays/s), so they keep the inlined form.
 template <typename P>
-RT_DEV D3 surface_colour(P img, const SceneView& sv, const DMaterial& m, int ref, D3 point) {
-    if (m.texture < 0) return ld3(m.diffuse);
+#if RT_TEXTURE_CALL
+__device__ __attribute__((noinline))
+#else
+RT_DEV
+#endif
+D3 textured_colour(P img, const SceneView& sv, const DMaterial& m, int ref, D3 point) {
     double u, v;
     prim_uv(img, sv, ref, point, u, v);
     return texture_color(sv, m, u, v);
+}
+template <typename P>
+RT_DEV D3 surface_colour(P img, const SceneView& sv, const DMaterial& m, int ref, D3 point) {
+    if (m.texture < 0) return ld3(m.diffuse);
+    return textured_colour(img, sv, m, ref, point);
 }
 
 // toneMap (RayTracer.cpp:161-202)
