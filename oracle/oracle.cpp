@@ -108,7 +108,7 @@ struct Rng {
 // node 1; the reflect/mirror/diffuse child of node c is 2c, the refract child 2c+1.
 enum : uint32_t {
     DIM_JITTER_X = 0, DIM_JITTER_Y = 1, DIM_LENS0 = 2,  // camera node
-    DIM_RR = 0, DIM_HEMI_1 = 1, DIM_HEMI_2 = 2, DIM_LIGHT0 = 4  // hit nodes
+    DIM_RR = 0, DIM_HEMI_1 = 2, DIM_HEMI_2 = 3, DIM_LIGHT0 = 4  // hit nodes (the two hemisphere dimensions share one counter block)
 };
 
 // ---------------------------------------------------------------------------------------------

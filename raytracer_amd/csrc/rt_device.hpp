@@ -1008,7 +1008,7 @@ RT_DEV void advance_whitted(P img, const SceneView& sv, const RenderArgs& A, con
 // Path-trace continuation (traceRayPath / estimateDirectLight, RayTracer.cpp:506-689)
 // ------------------------------------------------------------------------------------------------
 enum { PT_LIGHTS = 0, PT_MIRROR = 1, PT_GLASS_R = 2, PT_GLASS_T = 3, PT_DIFFUSE = 4 };
-enum { DIM_RR = 0, DIM_HEMI_1 = 1, DIM_HEMI_2 = 2, DIM_LIGHT0 = 4 };
+enum { DIM_RR = 0, DIM_HEMI_1 = 2, DIM_HEMI_2 = 3, DIM_LIGHT0 = 4 };  // (the two hemisphere dimensions share one counter block)
 
 RT_DEV D3 reflect_v(D3 v, D3 n) { return v - n * 2.0 * dot(v, n); }  // RayTracer.cpp:477-481
 RT_DEV D3 refract_v(D3 I, D3 N, double eta_t, double eta_i) {        // RayTracer.cpp:430-448
