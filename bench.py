@@ -274,7 +274,8 @@ class Bench:
         achieved = alg_ops / self.world / ((k_ms if F == 1 else ms_per_step) * 1e-3) / 1e12
         roof = {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VALU_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
-                "kernel": "fw_roots_kernel (level 0) + fw_kernel (depth >= 1: fused trace/shadow/shade per level, combine, tone map)",
+                "kernel": "fw_roots_kernel (level 0: trace, shadow rays, shade) + fw_kernel (depth >= 1, per level: trace + child rays, then the "
+                          "lights of the hits whose local colour is needed; combine, tone map)",
                 "kernel_ms": k_ms, "launches_in_flight": F, "workgroups_per_launch": G or "all",
                 # one launch's own rate (ops of one launch / its duration): with F launches in flight it runs on
                 # 1/F of the chip, so `achieved` is the ops of all launches over the timed region instead
@@ -353,8 +354,8 @@ class Bench:
         n_batches = -(-(side * side) // 4)
         roof = {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VALU_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
-                "kernel": "pt_kernel (per batch of 4 strata; per depth: trace, light = shadow rays + direct light, shade; "
-                          "combine) + bw_accumulate_path_kernel",
+                "kernel": "pt_kernel (per batch of 4 strata; per depth: trace, classify hits dark / clear / general, light = shadow "
+                          "rays + direct light, shade; combine) + bw_accumulate_path_kernel",
                 "kernel_ms": k_ms, "kernel_ms_per_launch": k_ms / max(n_batches // self.world, 1),
                 "launches_per_step": max(n_batches // self.world, 1), "launches_in_flight": 1, "workgroups_per_launch": "all",
                 "ops_per_ray": alg_ops / max(rays, 1.0), "reference_box_tests_per_ray": boxes / max(rays, 1.0),
