@@ -45,6 +45,13 @@ constexpr int kTraceBlock = RT_TRACE_BLOCK;  // threads per workgroup of the fra
 #ifndef RT_FUSED_BLOCK
 #define RT_FUSED_BLOCK 768
 #endif
+#ifndef RT_PT_BLOCK
+#define RT_PT_BLOCK RT_TRACE_BLOCK
+#endif
+#ifndef RT_PT_WAVES
+#define RT_PT_WAVES 4
+#endif
+constexpr int kPtBlock = RT_PT_BLOCK;  // pt_kernel's own workgroup size; RT_PT_WAVES waves per SIMD (128 registers) whatever it is
 #ifndef RT_FW_BLOCK
 #define RT_FW_BLOCK RT_FUSED_BLOCK
 #endif
