@@ -412,9 +412,91 @@ def cpu_baseline(sf, desc, base, pathtrace):
                     "itself, as built by its Makefile, measured 0.6-2.1 Mrays/s on 8 cores (BASELINE.md)"}
 
 
+def launch_command(n_gpus, argv, port):
+    """The command that starts one rank per GPU: what the driver itself runs for N > 1 (task brief), with this
+    invocation's own arguments handed to every rank."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()  # counts devices without initialising the GPU runtime in this process
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child job BEFORE this process
+    makes any GPU call, let rank 0's JSON line through on stdout, return the job's exit code."""
+    have = visible_gpus()
+    if have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} needs {args.gpus} visible GPUs, this box shows {have}: refusing to print a "
+              f"{args.gpus}-GPU line from fewer devices", file=sys.stderr)
+        return 2
+    cmd = launch_command(args.gpus, argv, free_port())
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd).returncode
+
+
+def group_bench(args):
+    """--mode group: ONE process, devices 0..N-1 behind rt_group_render_u8 (blocking: bands / strata ranges rendered side
+    by side, assembled on device 0 by peer copies, the PPM payload copied to the host).  The timed step therefore
+    includes the device-to-host copy of the frame's bytes, which the ranks mode (device-resident frames) does not."""
+    have = visible_gpus()
+    if have < args.gpus:
+        print(f"[bench] --mode group --gpus {args.gpus} needs {args.gpus} visible GPUs, this box shows {have}", file=sys.stderr)
+        return 2
+    import numpy as np
+    import raytracer_amd as rt
+    line = None
+    for workload in ("clutter_500_4k", "pathtrace_1080p"):
+        if args.workload not in ("both", workload):
+            continue
+        pt = workload == "pathtrace_1080p"
+        sf, desc, base = scene_setup(workload, args.spp)
+        g = rt.Group(list(range(args.gpus)))
+        g.load(sf, params=base, desc=desc)
+        steps, warmup = (max(args.pt_steps, 1), max(args.pt_warmup, 0)) if pt else (args.steps, args.warmup)
+        g.render_u8()  # the members size their node stores: not a warm-up step
+        for _ in range(warmup):
+            g.render_u8()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.render_u8()  # blocking
+        elapsed = time.perf_counter() - t0
+        st = g.stats()
+        g.close()
+        block = {"metric": "spp/s" if pt else "Mrays/s",
+                 "value": (int(np.sqrt(args.spp)) ** 2 / (elapsed / steps)) if pt else st.rays * steps / elapsed / 1e6,
+                 "unit": "spp/s at 1920x1080" if pt else "Mrays/s", "mrays_per_s": st.rays * steps / elapsed / 1e6,
+                 "n_gpus": args.gpus, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                 "data": "reference scene file, resized",
+                 "config": {"workload": workload, "rays_per_step": st.rays, "kernel_ms_slowest_member": st.kernel_ms,
+                            "parallelism": "rt_group x%d: one process, peer copies to device 0, frame bytes to the host "
+                                           "inside the timed step" % args.gpus}}
+        if line is None:
+            line = block
+        else:
+            line["pathtrace"] = block
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node that share ONE frame; N > 1 without WORLD_SIZE in the environment starts the N "
+                         "ranks itself (torch.distributed.run)")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "group"],
+                    help="ranks: one process per GPU + RCCL (default); group: ONE process driving devices 0..N-1 through "
+                         "rt_group_render_u8 (the C-ABI's own multi-GPU path)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="both", choices=["both", "clutter_500_4k", "pathtrace_1080p"])
@@ -436,8 +518,17 @@ def main():
         executed_counts_child(args.counts_child, args.spp)
         return
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.mode == "group":
+        sys.exit(group_bench(args))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
     do_w = args.workload in ("both", "clutter_500_4k")
     do_p = args.workload in ("both", "pathtrace_1080p")
     # child processes first, before this process touches the GPU
