@@ -280,6 +280,16 @@ struct rt_context {
     bool level_kernels = false;  // RT_PIPELINE=levels: one kernel per phase and depth instead of one per frame
     bool pt_exact = false;       // RT_PT_EXACT=1: pt_kernel evaluates an area-light sample in the reference's operation order (no regrouping)
     int pt_classes = 2;          // RT_PT_CLASSES=0: pt_kernel treats every hit as general; 1: dark hits only; 2: dark and clear-shaft hits
+    bool pt_queues = true;       // RT_PT_QUEUES=0 (or RT_PIPELINE=block): path trace with pt_kernel (levels per workgroup) where pq_kernel (queues per wave) applies
+    double* d_pq_stack = nullptr;    // pq_kernel: per-wave ray stacks
+    double* d_pq_hitq = nullptr;     //            per-wave hit queues
+    double* d_pq_val = nullptr;      //            traceRayPath's value per root of a launch
+    unsigned* d_pq_job = nullptr;    //            job counter
+    size_t pq_stack_bytes = 0, pq_val_bytes = 0, pq_hitq_bytes = 0, pq_job_bytes = 0;
+    unsigned long long pq_order_gen = 0;  // generation whose job order (most expensive first) d_pq_job holds
+    unsigned pq_order_jobs = 0;
+    int pq_order_batch = 0;
+    bool last_was_pq = false;
     bool pt_generic = false;     // RT_PT_GENERIC=1: path trace with bw_kernel<1> (any lights / sample counts) even where pt_kernel applies
     int fused = -1;              // one pass per level (fused_kernels.inc): -1 = Whitted yes, path trace no; RT_PIPELINE=fused / block force it
     unsigned* d_bw_info = nullptr;
@@ -369,6 +379,7 @@ int upload(T** dst, const std::vector<T>& src) {
 
 #include "wavefront_host.inc"
 #include "blockwave_host.inc"
+#include "pathqueue_host.inc"
 #include "static_host.inc"
 #include "gridwave_host.inc"
 
@@ -424,6 +435,8 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
         c->scene_in_lds = c->sv.lds_bytes <= kMaxLdsImage ? 1 : 0;
         if (c->level_kernels) return launch_wavefront(c, stream, A, accumulate_only);
         if (c->gridwave && p.mode != RT_MODE_PATHTRACE && p.max_depth > 0) return launch_gridwave(c, stream, A);
+        c->last_was_pq = pq_applies(c, A);
+        if (c->last_was_pq) return launch_pathqueue(c, stream, A, accumulate_only);
         return launch_blockwave(c, stream, A, accumulate_only);
     }
 
@@ -488,6 +501,7 @@ int frame_overflowed(rt_context* c, bool* out) {
     }
     if (overflow) {
         c->wf_calibrated_gen = 0;
+        if (c->last_was_pq) c->pt_queues = false;  // (a ray stack ran out, which pq_kernel's bound excludes: pt_kernel from now on)
         *out = true;
     }
     return RT_OK;
@@ -548,6 +562,8 @@ int rt_create(rt_context** out, int device) {
     c->fused = pipe && std::strcmp(pipe, "fused") == 0 ? 1 : (pipe && std::strcmp(pipe, "block") == 0 ? 0 : -1);
     c->gridwave = pipe && std::strcmp(pipe, "grid") == 0;
     if (const char* e = std::getenv("RT_SPLIT_ROOTS")) c->split_roots = std::atoi(e) != 0;
+    c->pt_queues = !(pipe && std::strcmp(pipe, "block") == 0);
+    if (const char* e = std::getenv("RT_PT_QUEUES")) c->pt_queues = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_PT_GENERIC")) c->pt_generic = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_PT_EXACT")) c->pt_exact = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_PT_CLASSES")) c->pt_classes = std::min(2, std::max(0, std::atoi(e)));
@@ -588,6 +604,10 @@ void rt_destroy(rt_context* c) {
     (void)hipFree(c->d_wf_shadow);
     (void)hipFree(c->d_wf_state);
     (void)hipFree(c->d_bw_info);
+    (void)hipFree(c->d_pq_stack);
+    (void)hipFree(c->d_pq_val);
+    (void)hipFree(c->d_pq_hitq);
+    (void)hipFree(c->d_pq_job);
     (void)hipFree(c->d_gw_lvl);
     (void)hipFree(c->d_gw_barrier);
     (void)hipFree(c->d_k1_count);

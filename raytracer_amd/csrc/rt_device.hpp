@@ -2,7 +2,7 @@
 // traversals, shading helpers (this file) and the kernel templates of the pipelines (the .inc files).  Everything
 // lives in an anonymous namespace: each .hip instantiates the kernels it exports and nothing else, so the
 // families compile in parallel (render_hip.hip: host side, per-pixel / level / grid kernels; k_blockwave.hip:
-// bw_kernel; k_fused.hip: fw_roots_kernel, fw_kernel; k_pathwave.hip: pt_kernel).
+// bw_kernel; k_fused.hip: fw_roots_kernel, fw_kernel; k_pathwave.hip: pt_kernel; k_pathqueue.hip: pq_kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -1387,5 +1387,6 @@ RT_DEV void advance_path(P img, const SceneView& sv, const RenderArgs& A, const 
 #include "blockwave_kernels.inc"
 #include "fused_kernels.inc"
 #include "pathwave_kernels.inc"
+#include "pathqueue_kernels.inc"
 
 }  // namespace
