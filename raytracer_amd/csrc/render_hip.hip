@@ -224,6 +224,19 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 11: r = div3(mk(x, 0.75 * x, -1.5 * x), y).x; break;  // D3 / double through one shared reciprocal when exact
         case 12: r = div3(mk(0.75 * x, -1.5 * x, x), y).z; break;
         case 13: r = sqrt_windowed(x); break;  // the library's sqrt without its rescaling wrapper when that is the identity
+        case 14: {  // pq_kernel's exact accumulator: x + y + 3 x - y as 96-bit fixed point (each term truncated to 2^-64), rounded once
+            unsigned long long lo = 0, l;
+            unsigned hi = 0, h;
+            const double t[4] = {x, y, 3.0 * x, -y};
+            for (int k = 0; k < 4; ++k) {
+                pq_fixed(t[k], l, h);
+                const unsigned long long old = lo;
+                lo += l;
+                hi += h + (lo < old ? 1u : 0u);
+            }
+            r = pq_acc_value(lo, (unsigned long long)(long long)(int)hi);
+            break;
+        }
         default: r = 0.0;
     }
     out[k] = r;
@@ -283,9 +296,8 @@ struct rt_context {
     bool pt_queues = true;       // RT_PT_QUEUES=0 (or RT_PIPELINE=block): path trace with pt_kernel (levels per workgroup) where pq_kernel (queues per wave) applies
     double* d_pq_stack = nullptr;    // pq_kernel: per-wave ray stacks
     double* d_pq_hitq = nullptr;     //            per-wave hit queues
-    double* d_pq_val = nullptr;      //            traceRayPath's value per root of a launch
     unsigned* d_pq_job = nullptr;    //            job counter
-    size_t pq_stack_bytes = 0, pq_val_bytes = 0, pq_hitq_bytes = 0, pq_job_bytes = 0;
+    size_t pq_stack_bytes = 0, pq_hitq_bytes = 0, pq_job_bytes = 0;
     unsigned long long pq_order_gen = 0;  // generation whose job order (most expensive first) d_pq_job holds
     unsigned pq_order_jobs = 0;
     int pq_order_batch = 0;
@@ -605,7 +617,6 @@ void rt_destroy(rt_context* c) {
     (void)hipFree(c->d_wf_state);
     (void)hipFree(c->d_bw_info);
     (void)hipFree(c->d_pq_stack);
-    (void)hipFree(c->d_pq_val);
     (void)hipFree(c->d_pq_hitq);
     (void)hipFree(c->d_pq_job);
     (void)hipFree(c->d_gw_lvl);

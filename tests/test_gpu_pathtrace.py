@@ -60,7 +60,7 @@ def test_general_kernel_equals_the_row_kernel():
     hit's light samples are added."""
     from tests.conftest import _make
     g = _make({"RT_PT_GENERIC": "1"})
-    r = _make({})
+    r = _make({"RT_PT_QUEUES": "0"})
     try:
         sf = scene_util.load("final", 120, 80)
         P = sf.params
@@ -79,7 +79,7 @@ def test_regrouped_light_sample_equals_the_reference_order():
     pdf folded into one weight, no second normalize of the unit direction); RT_PT_EXACT=1 keeps the reference's operation
     order.  Same rays; radiance within a few ulp per sample."""
     from tests.conftest import _make
-    e = _make({"RT_PT_EXACT": "1"})
+    e = _make({"RT_PT_EXACT": "1"})  # (both through pq_kernel, which shares the light sample's code with pt_kernel)
     r = _make({})
     try:
         for name, spp, ls in (("pathtrace", 16, 16), ("final", 4, 8)):
@@ -96,15 +96,18 @@ def test_regrouped_light_sample_equals_the_reference_order():
         e.close(); r.close()
 
 
-def test_hit_classes_change_no_bit():
-    """pt_kernel sorts a level's hits into dark (the whole light behind the surface or the hit behind the light: direct
+@pytest.mark.parametrize("queues", ["1", "0"])
+def test_hit_classes_change_no_bit(queues):
+    """(queues = 1: pq_kernel, the per-wave queues; 0: pt_kernel, the workgroup-wide levels -- both classify.)
+    pt_kernel sorts a level's hits into dark (the whole light behind the surface or the hit behind the light: direct
     light exactly 0), clear (the shaft from the hit to the light misses every other primitive's enlarged box: no any-hit
     walks) and general before its light phase.  Both shortcuts are exact: RT_PT_CLASSES=0 (every hit general) and
     RT_PT_CLASSES=1 (dark only) must give the same bits and the same ray count as the default, on the shipped scenes
     (open, closed box, textured, thin lens) and on random soups of all three primitive types -- glass and mirrors among
     them -- under randomly placed, tilted, large and small area lights."""
     from tests.conftest import _make
-    rs = [_make({"RT_PT_CLASSES": "0"}), _make({"RT_PT_CLASSES": "1"}), _make({})]
+    rs = [_make({"RT_PT_CLASSES": "0", "RT_PT_QUEUES": queues}), _make({"RT_PT_CLASSES": "1", "RT_PT_QUEUES": queues}),
+          _make({"RT_PT_QUEUES": queues})]
     try:
         cases = []
         for name, spp, ls in (("pathtrace", 4, 16), ("final", 4, 8), ("final_textured_lens", 4, 4), ("lens_sampling", 4, 2),
