@@ -381,3 +381,41 @@ def test_sample_range_and_band_partitions_recombine(renderer):
         rows = [j for j in range(64) if (j // 8) % 3 == rank]
         got[rows], _ = renderer.render(want_hit=False)
     assert np.array_equal(got, full)
+
+
+@pytest.mark.parametrize("queues", ["1", "0"])
+@pytest.mark.parametrize("gap", [5e-5, 2e-5, 9e-5, -5e-5])
+def test_occluder_within_the_bias_of_the_light(queues, gap):
+    """A shadow segment starts bias = 1e-4 off the surface along the normal and keeps the length |X - P|: it ends bias
+    BEYOND the light point X (RayTracer.cpp:649-651).  A ceiling `gap` < bias behind a downward-facing light therefore
+    shadows every sample of an upward-facing floor in the reference (gap < 0: a sheet just in front of the light does so
+    anyway); a wall beside the light is grazed by the shifted segments only.  The "clear" class must see both: frames with
+    and without the hit classes agree bit for bit, and with the oracle."""
+    from tests import oracle_lib
+    from tests.conftest import _make
+    T = rt.capi.RT_TRIANGLE
+    y = 1.5 + gap
+    tris = [((-3, -0.5, -3), (3, -0.5, -3), (3, -0.5, 3)), ((-3, -0.5, -3), (3, -0.5, 3), (-3, -0.5, 3)),   # floor
+            ((-2, y, -2), (2, y, -2), (0, y, 3)),                                                                # ceiling behind the light
+            ((0.5 + gap, 0.0, -2), (0.5 + gap, 3.0, -2), (0.5 + gap, 1.5, 3))]                                   # wall beside it
+    geom = np.zeros((len(tris), rt.capi.RT_GEOM_STRIDE))
+    for k, (a, b, c) in enumerate(tris):
+        geom[k, 0:3], geom[k, 3:6], geom[k, 6:9] = a, b, c
+    light = scene_util.area_light((0.0, 1.5, 0.3), (0, -1, 0), (1, 0, 0), (0, 0, 1), 1.0, 1.0)
+    syn = scene_util.SyntheticScene(np.full(len(tris), T, dtype=np.int32), geom, materials=[scene_util.default_material()], lights=[light], use_bvh=1)
+    cam = scene_util.look_at((-2.0, 1.0, 0.0), (0.0, -0.1, 1.0), aspect=1.5)
+    P = scene_util.make_params(120, 80, mode=rt.RT_MODE_PATHTRACE, max_depth=3, pixel_samples=4, light_samples=16)
+    out = []
+    for classes in ("2", "0"):
+        r = _make({"RT_PT_CLASSES": classes, "RT_PT_QUEUES": queues})
+        try:
+            r.upload(syn.desc); r.set_camera(cam); r.set_params(P)
+            rgb, _ = r.render(want_hit=False)
+            out.append((rgb, r.stats().rays))
+        finally:
+            r.close()
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0])
+    orgb, _, cnt, _ = oracle_lib.render(syn.desc, cam, P, want_hit=False)
+    assert cnt["rays"] == out[0][1]
+    assert (np.abs(out[0][0] - orgb).max(axis=2) > 1e-9).mean() <= 1e-3
