@@ -161,7 +161,7 @@ class Bench:
             rw.render_u8()
         st = rw.stats()
         rw.close()
-        return [st.rays, st.box_tests, st.sphere_tests, st.triangle_tests, st.cylinder_tests]
+        return [st.rays, st.box_tests, st.sphere_tests, st.triangle_tests, st.cylinder_tests, st.unwalked_ops]
 
     def reduce_counts(self, ref_counts, elapsed_list, kernel_ms):
         torch, dist = self.torch, self.dist
@@ -263,7 +263,7 @@ class Bench:
             r.close()
 
         regions, cnt, k_ms = self.reduce_counts(ref_counts, regions, float(np.median(kernel_ms)))
-        rays, boxes, sph, tri, cyl = cnt
+        rays, boxes, sph, tri, cyl, unwalked_ops = cnt
         elapsed = float(np.median(regions))
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays * args.steps / elapsed / 1e6
@@ -272,8 +272,12 @@ class Bench:
         # share of the chip only, so the chip's rate is the ops of all launches of the timed region over
         # that region (a lower bound: it includes the gaps between kernels).
         achieved = alg_ops / self.world / ((k_ms if F == 1 else ms_per_step) * 1e-3) / 1e12
+        walked = (alg_ops - unwalked_ops) / alg_ops
         roof = {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VALU_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
+                # the same numerator without the reference-order tests of rays that are counted but not walked (shadow rays of
+                # hits whose local colour RayTracer.cpp:798 overwrites), counted by the same walk frame
+                "frac_walked": achieved * walked / FP64_VALU_PEAK_TOPS, "walked_ops_share": walked,
                 "kernel": "fw_roots_kernel (level 0: trace, shadow rays, shade) + fw_kernel (depth >= 1, per level: trace + child rays, then the "
                           "lights of the hits whose local colour is needed; combine, tone map)",
                 "kernel_ms": k_ms, "launches_in_flight": F, "workgroups_per_launch": G or "all",
@@ -345,23 +349,40 @@ class Bench:
         assert st.rays == ref_counts[0], "the production traversal must trace exactly the reference's rays"
         r.close()
 
+        launches = max(int(st.kernel_launches), 1)
         (elapsed,), cnt, k_ms = self.reduce_counts(ref_counts, [elapsed], k_ms)
-        rays, boxes, sph, tri, cyl = cnt
+        rays, boxes, sph, tri, cyl, unwalked_ops = cnt
         ms_per_step = elapsed / steps * 1e3
         mrays = rays * steps / elapsed / 1e6
         alg_ops = OPS_BOX * boxes + OPS_SPHERE * sph + OPS_TRI * tri + OPS_CYL * cyl  # per frame, all ranks
         achieved = alg_ops / self.world / (k_ms * 1e-3) / 1e12
-        n_batches = -(-(side * side) // 4)
+        walked = (alg_ops - unwalked_ops) / alg_ops
+        # Second numerator: what the reference computes per light sample besides the shadow ray's intersection, counted from its
+        # expressions like SURVEY 8(d) counts a box test -- AreaLight::sample (AreaLight.cpp:3-20: two offsets 4, point 12,
+        # direction 3, length 6, three divisions 3, area 1, cosine 6, pdf 3 = 38), the shadow ray (origin 6, normalize 9 = 15)
+        # and, where the sample is neither occluded nor back-facing, the BRDF and the term (RayTracer.cpp:655-679: two cosines 12,
+        # diffuse 6, half vector 12, n.h 6, pow 1, specular 12, sum 3, term 12, += 3 = 67).  53 ops for every counted shadow ray
+        # is therefore a LOWER bound of the reference's own per-sample fp64 arithmetic (the RNG draws are not priced).
+        S = PT_LIGHT_SAMPLES
+        shadow_rays = rays * S / (S + 1.0)
+        sample_ops = 53.0 * shadow_rays
         roof = {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VALU_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TOPS, "traffic": None,
-                "kernel": "pt_kernel (per batch of 4 strata; per depth: trace, classify hits dark / clear / general, light = shadow "
-                          "rays + direct light, shade; combine) + bw_accumulate_path_kernel",
-                "kernel_ms": k_ms, "kernel_ms_per_launch": k_ms / max(n_batches // self.world, 1),
-                "launches_per_step": max(n_batches // self.world, 1), "launches_in_flight": 1, "workgroups_per_launch": "all",
+                # only the reference-order tests of rays that are walked (not: shadow rays of dark and clear hits)
+                "frac_walked": achieved * walked / FP64_VALU_PEAK_TOPS, "walked_ops_share": walked,
+                # ... and with the per-sample arithmetic of the reference priced in (lower bound, see bench.py)
+                "frac_with_sampling": (alg_ops + sample_ops) / self.world / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
+                "sampling_ops_per_shadow_ray": 53.0,
+                "kernel": ("pq_kernel (one launch per 64 strata; every wave on its own: ray pass = 64 stacked rays or new roots -> closest "
+                           "hit; hit pass = 64 hits -> class dark / clear / general, material branch, child rays; light pass = 4 hits x "
+                           "16 samples; exact per-pixel sums added to the frame)") if os.environ.get("RT_PT_QUEUES", "1") != "0" else
+                          "pt_kernel (per batch of 4 strata; per depth: trace, classify, light, shade; combine) + bw_accumulate_path_kernel",
+                "kernel_ms": k_ms, "kernel_ms_per_launch": k_ms / launches,
+                "launches_per_step": launches, "launches_in_flight": 1, "workgroups_per_launch": "all",
                 "ops_per_ray": alg_ops / max(rays, 1.0), "reference_box_tests_per_ray": boxes / max(rays, 1.0),
-                "note": "fp64 ops without FMA credit; numerator = the REFERENCE's box / primitive tests (SURVEY 8(d)): the "
-                        "sampling work of a shadow ray (Philox, AreaLight::sample, BRDF: about as many instructions as its "
-                        "traversal) is not in it"}
+                "note": "fp64 ops without FMA credit; numerator of `frac` = the REFERENCE's box / primitive tests (SURVEY 8(d)); "
+                        "frac_walked drops the tests of rays that are counted but not walked, frac_with_sampling adds the reference's "
+                        "per-sample arithmetic"}
         block = {"metric": "spp/s", "value": side * side / (elapsed / steps), "unit": "spp/s at 1920x1080",
                  "mrays_per_s": mrays, "n_gpus": self.world, "steps": steps, "warmup": max(args.pt_warmup, 0),
                  "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "dtype": "f64",
@@ -543,9 +564,10 @@ def main():
             if exe_w:
                 line["roofline"].update(exe_w)
                 add_executed_rates(line, line["roofline"], line["config"]["rays_per_step"], line["ms_per_step"])
-            q = quoted_profile("r02_clutter_500_pmc.json")
+            q = quoted_profile("r03_clutter_500_pmc.json")
             if q and world == 1:
                 line["roofline"]["traffic"] = q.get("hbm_bytes_per_frame")
+                line["roofline"]["traffic_fetch_raw"] = q.get("hbm_bytes_per_frame_fetch_raw")
                 line["roofline"]["valu_busy"] = q.get("valu_busy")
                 line["roofline"]["lane_utilisation"] = q.get("lane_utilisation")
                 line["roofline"]["pmc_quoted_from"] = q["quoted_from"] + " (" + q.get("source", "") + ")"
@@ -557,9 +579,11 @@ def main():
             if exe_p:
                 block["roofline"].update(exe_p)
                 add_executed_rates(block, block["roofline"], block["config"]["rays_per_step"], block["ms_per_step"])
-            q = quoted_profile("r02_pathtrace_pmc.json")
+            q = quoted_profile("r03_pathtrace_pmc.json")
             if q and world == 1:
                 block["roofline"]["traffic"] = q.get("hbm_bytes_per_launch")
+                block["roofline"]["traffic_fetch_raw"] = q.get("hbm_bytes_per_launch_fetch_raw")
+                block["roofline"]["traffic_strata_per_launch"] = q.get("strata_per_launch")
                 block["roofline"]["valu_busy"] = q.get("valu_busy")
                 block["roofline"]["lane_utilisation"] = q.get("lane_utilisation")
                 block["roofline"]["pmc_quoted_from"] = q["quoted_from"] + " (" + q.get("source", "") + ")"

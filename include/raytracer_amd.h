@@ -167,6 +167,12 @@ typedef struct rt_stats {
                               * of a path-traced hit the light cannot reach or see) is counted in `rays`
                               * but not walked.  Counted like box_tests: 0 for the default traversal
                               * unless built with -DRT_FBVH_COUNTS=1                              */
+    int32_t kernel_launches; /* launches of the frame's main kernel in the last render (path trace: one per
+                              * batch of strata; Whitted: 1): kernel_ms / kernel_launches prices one launch */
+    int32_t reserved;
+    uint64_t unwalked_ops;   /* RT_TRAVERSAL=walk / cull only: of the box / primitive tests counted above, those of rays
+                              * the production traversal does not walk, priced as SURVEY.md 8(d) prices them (24 per box,
+                              * 33 / 62 / 150 per sphere / triangle / cylinder test); the roofline's `frac_walked` */
 } rt_stats;
 
 typedef struct rt_context rt_context;       /* device-side renderer, one per GPU             */

@@ -81,6 +81,9 @@ class Stats(C.Structure):
         ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
         ("n_bvh_nodes", C.c_int32), ("scene_in_lds", C.c_int32),
         ("rays_traversed", C.c_uint64),
+        ("kernel_launches", C.c_int32),
+        ("reserved", C.c_int32),
+        ("unwalked_ops", C.c_uint64),
     ]
 
 

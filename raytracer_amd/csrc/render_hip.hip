@@ -302,6 +302,7 @@ struct rt_context {
     unsigned pq_order_jobs = 0;
     int pq_order_batch = 0;
     bool last_was_pq = false;
+    int last_launches = 1;  // launches of the frame's main kernel in the last render (rt_stats.kernel_launches)
     bool pt_generic = false;     // RT_PT_GENERIC=1: path trace with bw_kernel<1> (any lights / sample counts) even where pt_kernel applies
     int fused = -1;              // one pass per level (fused_kernels.inc): -1 = Whitted yes, path trace no; RT_PIPELINE=fused / block force it
     unsigned* d_bw_info = nullptr;
@@ -441,6 +442,7 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     A.counters = c->d_counters;
 
     c->last_counters = c->d_counters;
+    c->last_launches = 1;
     if (static_workspace) return launch_fused_static(c, stream, A);
     c->last_was_wavefront = c->wavefront;
     if (c->wavefront) {
@@ -1075,9 +1077,11 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
                           hipMemcpyDeviceToHost));
         unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t r = 0; r < (size_t)kCounterSlots; ++r)
-            for (int k = 0; k < 6; ++k) cnt[k] += rows[r * kCounterRow + k];
+            for (int k = 0; k < 7; ++k) cnt[k] += rows[r * kCounterRow + k];
         out->rays = cnt[0];
         out->rays_traversed = cnt[5];
+        out->kernel_launches = c->last_launches;
+        out->unwalked_ops = cnt[6];
         out->box_tests = cnt[1];
         out->sphere_tests = cnt[2];
         out->triangle_tests = cnt[3];

@@ -151,7 +151,20 @@ struct HitT {
 struct Tally {
     unsigned rays, box, sph, tri, cyl;
     unsigned walks;  // traversals actually started (trace_ray): below `rays` where a ray's answer cannot reach the image and is not computed
+    // Counting traversals (walk / cull) only: of the tests above, those of rays the PRODUCTION traversal would not walk --
+    // shadow rays of a Whitted hit whose local colour is dead, of a path-traced hit that is dark or clear -- priced as
+    // SURVEY.md 8(d) prices them (24 per box, 33 / 62 / 150 per sphere / triangle / cylinder test).
+    unsigned unwalked_ops;
 };
+// a traversal that was counted into `t` on behalf of such a ray
+RT_DEV void tally_unwalked(Tally& tally, const Tally& t) {
+    tally.box += t.box;
+    tally.sph += t.sph;
+    tally.tri += t.tri;
+    tally.cyl += t.cyl;
+    tally.walks += t.walks;
+    tally.unwalked_ops += 24u * t.box + 33u * t.sph + 62u * t.tri + 150u * t.cyl;
+}
 
 // Adds a wave's tallies to the row this wave owns (rows are per (block, wave); kernels on one
 // stream run one after another, so a plain read-modify-write is enough).  4096 waves doing 5
@@ -159,19 +172,19 @@ struct Tally {
 // `overwrite`: the first kernel of a frame stores instead of adding, which spares the host a 2 MB memset per
 // frame (a fill kernel that has to wait for a free CU when several frames are in flight).
 RT_DEV void flush_tally(const Tally& tally, unsigned long long* counters, bool overwrite = false) {
-    unsigned long long c[6] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl, tally.walks};
+    unsigned long long c[7] = {tally.rays, tally.box, tally.sph, tally.tri, tally.cyl, tally.walks, tally.unwalked_ops};
     for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 6; ++k) c[k] += __shfl_down(c[k], off);
+        for (int k = 0; k < 7; ++k) c[k] += __shfl_down(c[k], off);
     if ((threadIdx.x & 63) == 0) {
         unsigned row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (row < (unsigned)kCounterSlots) {
             unsigned long long* r = counters + (size_t)row * kCounterRow;
             if (overwrite)
-                for (int k = 0; k < 6; ++k) r[k] = c[k];
+                for (int k = 0; k < 7; ++k) r[k] = c[k];
             else
-                for (int k = 0; k < 6; ++k) r[k] += c[k];
+                for (int k = 0; k < 7; ++k) r[k] += c[k];
         } else {
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < 7; ++k)
                 if (c[k]) atomicAdd(&counters[k], c[k]);
         }
     }

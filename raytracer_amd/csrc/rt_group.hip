@@ -326,6 +326,8 @@ int rt_group_get_stats(rt_group* g, rt_stats* out) {
         RT_TRY(rt_get_stats(me.ctx, &st));
         out->rays += st.rays;
         out->rays_traversed += st.rays_traversed;
+        out->unwalked_ops += st.unwalked_ops;
+        out->kernel_launches = std::max(out->kernel_launches, st.kernel_launches);
         out->box_tests += st.box_tests;
         out->prim_tests += st.prim_tests;
         out->sphere_tests += st.sphere_tests;

@@ -8,7 +8,10 @@ name, w, h, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]
 sf = rt.SceneFile(f"scenes/{name}.json", width=w, height=h)
 desc = sf.desc; desc.use_bvh = 1
 P = sf.params
-if P.mode == 2: P.pixel_samples, P.light_samples = 16, 16
+spp = 16
+for a in sys.argv[5:]:
+    if a.startswith("spp"): spp = int(a[3:])
+if P.mode == 2: P.pixel_samples, P.light_samples = spp, 16
 r = rt.Renderer(0)
 r.upload(desc); r.set_camera(sf.camera); r.set_params(P)
 u8 = len(sys.argv) > 5 and sys.argv[5] == "u8"  # PPM bytes straight from the kernels, as bench.py renders
