@@ -62,3 +62,28 @@ def test_static_workspace_limits(renderer):
     rgb, hit = renderer.render()
     orgb, ohit, _, _ = oracle_lib.render(sf.desc, sf.camera, sf.params)
     assert np.array_equal(hit, ohit) and np.abs(rgb - orgb).max() <= 1e-12
+
+
+def test_static_workspace_under_stream_capture(renderer):
+    """The entry point inside a captured HIP graph (torch.cuda.graph: the stream handed over is capturing), replayed twice
+    into a cleared buffer: the frame of the allocating entry point both times.  One call outside capture comes first -- it
+    makes the setup's attribute / occupancy queries -- and rt_get_stats after the replays reports no overflow."""
+    import torch
+    w, h = 200, 120
+    sf = scene_util.load("mirror_glass_cylinder", w, h)
+    renderer.load(sf, sf.params)
+    ref8 = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+    renderer.render_device_u8(ref8.data_ptr(), None, None, stream=torch.cuda.current_stream().cuda_stream)
+    got8 = torch.zeros_like(ref8)
+    renderer.render_device_u8_static(got8.data_ptr(), None, None, stream=torch.cuda.current_stream().cuda_stream)  # warm-up, outside capture
+    torch.cuda.synchronize()
+    assert torch.equal(got8, ref8)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        renderer.render_device_u8_static(got8.data_ptr(), None, None, stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        got8.fill_(77)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got8, ref8)
+    renderer.stats()  # (raises if a replay had overflowed the workspace)
