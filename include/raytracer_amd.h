@@ -145,8 +145,12 @@ typedef struct rt_params {
      * [sample_begin, sample_end); sample_end <= 0 means "all". */
     int32_t sample_begin;
     int32_t sample_end;
-    int32_t reserved1;
+    int32_t debug_flags; /* 0 in production.  RT_DEBUG_NO_JITTER (path trace): every stratum is sampled at its lower-left
+                          * corner instead of a random point (r1 = sx / sqrt_nspp, r2 = sy / sqrt_nspp, RayTracer.cpp:273-274); with
+                          * pixelSamples 1 the camera rays are render()'s (u = 1 - i/(W-1), v = j/(H-1), :217-218), which lets the
+                          * parity tests drive traceRayPath on the rays of tests/golden/unit_vectors.npz */
 } rt_params;
+enum { RT_DEBUG_NO_JITTER = 1 };
 
 typedef struct rt_stats {
     uint64_t rays;         /* closest-hit queries traced by the last render (= Scene::intersect
@@ -272,7 +276,10 @@ int rt_render_device_u8(rt_context* ctx, void* stream, uint8_t* rgb8_dev, double
  * rt_render_device_u8); a frame whose ray forest outgrows the array sets the context's overflow flag, reported by
  * the next call on the context or by rt_get_stats as for rt_render_device_u8.  Every call on a GPU shares that GPU's
  * array, whichever context makes it: calls that overlap on one GPU (two streams, two contexts, two threads) race --
- * serialize them.  The pipeline-selection variables of rt_create (RT_PIPELINE, RT_SPLIT_ROOTS) must be unset. */
+ * serialize them.  The pipeline-selection variables of rt_create (RT_PIPELINE, RT_SPLIT_ROOTS) must be unset.
+ * Under HIP stream capture: make one call of the setup OUTSIDE capture first (it makes the attribute / occupancy queries);
+ * a captured call records no timing events (rt_get_stats then has no kernel_ms / ray count for it) and the overflow word
+ * is read by the host at call time, not per replay -- poll it with rt_get_stats after replays. */
 int rt_render_device_u8_static(rt_context* ctx, void* stream, uint8_t* rgb8_dev, double* rgb_dev, int32_t* hit_id_dev);
 
 /* Caps the grid of the persistent render kernels at n_workgroups (0 = as many as the chip holds, the
@@ -334,7 +341,10 @@ int rt_debug_math(rt_context* ctx, int op, int64_t n, const double* a, const dou
 /* op 0: n rows in[k] = (I xyz, N xyz, eta_t, eta_i) -> out[k] = (refract xyz, 1 if length(normalize(refract)) > 0 else 0
  * [the transmission test of RayTracer.cpp:572], reflect xyz, fresnel, fresnelReflectance(|I.N|, eta_t)), the device's
  * restatement of RayTracer.cpp:430-504.  op 1: n rows of colours (3) -> toneMap for NONE, REINHARD, WARD, UNCHARTED2 (12),
- * RayTracer.cpp:161-202.  Checked against the reference's own functions (tests/golden/unit_vectors.npz). */
+ * RayTracer.cpp:161-202.  op 2: n rows (primitive ID, point xyz) of the uploaded scene -> (u, v) of the primitive's getUV
+ * (Sphere.cpp:50-57, Triangle.cpp:15-39, Cylinder.cpp:109-129) and its material's getTextureColor(u, v) (Material.cpp:69-86),
+ * 5 values; op 3: n rows (primitive ID, u, v, unused) -> the same with the given (u, v).
+ * Checked against the reference's own functions (tests/golden/unit_vectors.npz). */
 int rt_debug_optics(rt_context* ctx, int op, int64_t n, const double* in, double* out);
 
 #ifdef __cplusplus

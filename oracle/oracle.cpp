@@ -888,8 +888,9 @@ int oracle_render(const rt_scene_desc* desc, const rt_camera* cam, const rt_para
                         int s = sy * sq + sx;
                         if (s < s_begin || s >= s_end) continue;
                         rng.sample = (uint32_t)s;
-                        double r1 = (sx + rng.u(0, DIM_JITTER_X)) / sq;
-                        double r2 = (sy + rng.u(0, DIM_JITTER_Y)) / sq;
+                        const bool jitter = !(P->debug_flags & RT_DEBUG_NO_JITTER);
+                        double r1 = (sx + (jitter ? rng.u(0, DIM_JITTER_X) : 0.0)) / sq;
+                        double r2 = (sy + (jitter ? rng.u(0, DIM_JITTER_Y) : 0.0)) / sq;
                         double u = 1.0 - (double(i) + r1) / (W - 1);
                         double v = (double(j) + r2) / (H - 1);
                         Ray ray = camera_ray(C, u, v, true, &rng);
@@ -995,6 +996,46 @@ void oracle_optics(int64_t n, const double* in, double* out) {
         o[7] = Renderer::fresnel(I, N, r[6], r[7]);
         o[8] = Renderer::schlick(std::fabs(dot(I, N)), r[6]);
     }
+}
+
+// estimateDirectLight (RayTracer.cpp:598-689) at the closest hit of n caller-supplied rays (directions normalized by the Ray
+// constructor), view direction = -ray.direction.normalize() as traceRayPath passes it (:539): out row = (hit, direct xyz).
+// Deterministic for point lights; area-light samples draw from the stream of pixel 0, stratum 0, node 1.
+int oracle_direct_light(const rt_scene_desc* desc, const rt_params* P, int64_t n, const double* origins, const double* dirs, double* out) {
+    Scene sc;
+    load_scene(desc, sc);
+    Renderer R(sc, *P);
+    for (int64_t k = 0; k < n; ++k) {
+        Counters c;
+        Ray r(V3(origins + 3 * k), V3(dirs + 3 * k));
+        Hit h;
+        const bool ok = sc.intersect(r, h, c);
+        Rng rng;
+        rng.key[0] = (uint32_t)P->seed;
+        rng.key[1] = (uint32_t)(P->seed >> 32);
+        rng.pixel = 0;
+        rng.sample = 0;
+        const V3 d = ok ? R.direct_light(h, -normalize(r.d), rng, 1, c) : V3(0, 0, 0);
+        out[4 * k] = ok ? 1.0 : 0.0;
+        out[4 * k + 1] = d.x; out[4 * k + 2] = d.y; out[4 * k + 3] = d.z;
+    }
+    return 0;
+}
+
+// getUV of primitive prim[k] at point[k] (Sphere.cpp:50-57, Triangle.cpp:15-39, Cylinder.cpp:109-129), then
+// Material::getTextureColor of that primitive's material at (u, v) (Material.cpp:69-86): out row = (u, v, r, g, b).
+// uv_in != NULL: skip getUV and look the texture up at the given (u, v).
+int oracle_uv_texture(const rt_scene_desc* desc, int64_t n, const int32_t* prim, const double* points, const double* uv_in, double* out) {
+    Scene sc;
+    load_scene(desc, sc);
+    for (int64_t k = 0; k < n; ++k) {
+        double u, v;
+        if (uv_in) { u = uv_in[2 * k]; v = uv_in[2 * k + 1]; }
+        else sc.prim_uv(prim[k], V3(points + 3 * k), u, v);
+        const V3 c = sc.texture_color(sc.mats[sc.prims[prim[k]].material], u, v);
+        out[5 * k] = u; out[5 * k + 1] = v; out[5 * k + 2] = c.x; out[5 * k + 3] = c.y; out[5 * k + 4] = c.z;
+    }
+    return 0;
 }
 
 void oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }

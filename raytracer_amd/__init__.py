@@ -159,9 +159,9 @@ class Renderer:
         return out
 
     def optics(self, op, rows):
-        """rt_debug_optics: op 0 rows [n, 8] -> [n, 9], op 1 colours [n, 3] -> [n, 12]."""
+        """rt_debug_optics: op 0 rows [n, 8] -> [n, 9], op 1 colours [n, 3] -> [n, 12], op 2 / 3 rows [n, 4] -> [n, 5]."""
         a = np.ascontiguousarray(rows, dtype=np.float64)
-        out = np.empty((a.shape[0], 9 if op == 0 else 12), dtype=np.float64)
+        out = np.empty((a.shape[0], {0: 9, 1: 12}.get(op, 5)), dtype=np.float64)
         capi.check(self._lib.rt_debug_optics(self._h, op, a.shape[0], a.ctypes.data, out.ctypes.data), "rt_debug_optics")
         return out
 

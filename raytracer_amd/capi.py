@@ -15,6 +15,7 @@ RT_SPHERE, RT_TRIANGLE, RT_CYLINDER = 0, 1, 2
 RT_MODE_PHONG, RT_MODE_BINARY, RT_MODE_PATHTRACE = 0, 1, 2
 RT_TONEMAP_NONE, RT_TONEMAP_REINHARD, RT_TONEMAP_WARD, RT_TONEMAP_UNCHARTED2 = 0, 1, 2, 3
 RT_LIGHT_POINT, RT_LIGHT_AREA = 0, 1
+RT_DEBUG_NO_JITTER = 1  # rt_params.debug_flags
 
 d3 = C.c_double * 3
 
@@ -70,7 +71,7 @@ class Params(C.Structure):
         ("exposure", C.c_double), ("shadow_bias", C.c_double),
         ("seed", C.c_uint64),
         ("band_rows", C.c_int32), ("band_rank", C.c_int32), ("band_world", C.c_int32),
-        ("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("reserved1", C.c_int32),
+        ("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("debug_flags", C.c_int32),
     ]
 
 

@@ -172,10 +172,19 @@ __global__ void debug_trace_kernel(SceneView sv, int fast, long long n, const do
 
 // rows of (I, N, eta_t, eta_i) -> (refract, transmits, reflect, fresnel, fresnelReflectance); rows of colours -> the
 // four tone maps: the device functions of RayTracer.cpp:430-504 and :161-202 on chosen inputs
-__global__ void debug_optics_kernel(int op, long long n, const double* in, double* out) {
+__global__ void debug_optics_kernel(int op, long long n, const double* in, double* out, SceneView sv) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    if (op == 0) {
+    if (op >= 2) {  // getUV of a primitive of the uploaded scene and its material's getTextureColor (op 3: at a given (u, v))
+        const double* r = in + 4 * k;
+        const int ref = ((const int*)(sv.image + sv.off_ref))[(int)r[0]];
+        const DMaterial& m = material_of(sv.image, sv, ref);
+        double u = r[1], v = r[2];
+        if (op == 2) prim_uv(sv.image, sv, ref, ld3(r + 1), u, v);
+        const D3 c = texture_color(sv, m, u, v);
+        double* o = out + 5 * k;
+        o[0] = u; o[1] = v; o[2] = c.x; o[3] = c.y; o[4] = c.z;
+    } else if (op == 0) {
         const double* r = in + 8 * k;
         double* o = out + 9 * k;
         D3 I = ld3(r), N = ld3(r + 3);
@@ -435,6 +444,7 @@ int launch_render(rt_context* c, hipStream_t stream, double* rgb_dev, int* hit_d
     A.seed_lo = (unsigned)(p.seed & 0xFFFFFFFFull);
     A.seed_hi = (unsigned)(p.seed >> 32);
     A.accumulate_only = accumulate_only ? 1 : 0;
+    A.no_jitter = (p.debug_flags & RT_DEBUG_NO_JITTER) ? 1 : 0;
     A.rgb = rgb_dev;
     A.rgb8 = rgb8_dev;
     A.hit_id = hit_dev;
@@ -1087,15 +1097,17 @@ int rt_get_stats(rt_context* c, rt_stats* out) {
         out->triangle_tests = cnt[3];
         out->cylinder_tests = cnt[4];
         out->prim_tests = cnt[2] + cnt[3] + cnt[4];
-        bool overflowed = false;
-        int rc = frame_overflowed(c, &overflowed);
-        if (rc != RT_OK) return rc;
-        if (overflowed)
-            return rt::set_error(RT_ERR_LIMIT, "the last render overflowed its node store; its output is invalid, render again");
     }
     out->upload_ms = c->upload_ms;
     out->n_bvh_nodes = c->n_bvh_nodes;
     out->scene_in_lds = c->scene_in_lds;
+    // (also for a frame without timing events -- rt_render_device_u8_static under stream capture, whose replays the caller
+    // has waited for: the flag is one word of host memory)
+    bool overflowed = false;
+    int rc = frame_overflowed(c, &overflowed);
+    if (rc != RT_OK) return rc;
+    if (overflowed)
+        return rt::set_error(RT_ERR_LIMIT, "the last render overflowed its node store; its output is invalid, render again");
     return RT_OK;
 }
 
@@ -1134,17 +1146,22 @@ int rt_debug_trace_rays(rt_context* c, int64_t n, const double* origins, const d
 }
 
 int rt_debug_optics(rt_context* c, int op, int64_t n, const double* in, double* out) {
-    if (!c || n < 0 || !in || !out || op < 0 || op > 1) return rt::set_error(RT_ERR_INVALID, "rt_debug_optics: bad argument");
+    if (!c || n < 0 || !in || !out || op < 0 || op > 3) return rt::set_error(RT_ERR_INVALID, "rt_debug_optics: bad argument");
+    if (op >= 2 && !c->have_scene) return rt::set_error(RT_ERR_STATE, "rt_debug_optics: op %d needs an uploaded scene", op);
+    if (op >= 2)
+        for (int64_t k = 0; k < n; ++k)
+            if (!(in[4 * k] >= 0 && in[4 * k] < c->sv.n_prims)) return rt::set_error(RT_ERR_INVALID, "rt_debug_optics: row %lld: no such primitive", (long long)k);
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t in_bytes = (size_t)n * (op == 0 ? 8 : 3) * sizeof(double), out_bytes = (size_t)n * (op == 0 ? 9 : 12) * sizeof(double);
+    const int in_cols = op == 0 ? 8 : (op == 1 ? 3 : 4), out_cols = op == 0 ? 9 : (op == 1 ? 12 : 5);
+    const size_t in_bytes = (size_t)n * in_cols * sizeof(double), out_bytes = (size_t)n * out_cols * sizeof(double);
     double *d_in = nullptr, *d_out = nullptr;
     int rc = RT_OK;
     hipError_t e = hipMalloc((void**)&d_in, in_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_bytes);
     if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(debug_optics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, (long long)n, d_in, d_out);
+        hipLaunchKernelGGL(debug_optics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, (long long)n, d_in, d_out, c->sv);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);

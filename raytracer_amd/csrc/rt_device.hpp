@@ -129,6 +129,7 @@ struct RenderArgs {
     int tiles_x, total_items;
     unsigned int seed_lo, seed_hi;
     int accumulate_only;  // path trace: write raw sums
+    int no_jitter;        // rt_params.debug_flags & RT_DEBUG_NO_JITTER: strata sampled at their lower-left corner
     // outputs / workspace
     double* rgb;              // fp64 frame (may be null when rgb8 is given: Whitted / binary only)
     unsigned char* rgb8;      // or null: the PPM payload, int(255.999 * c) per component (RayTracer.cpp:359-362)
@@ -1135,8 +1136,8 @@ RT_DEV void pt_next_sample(const RenderArgs& A, const Frames& F, Lane& L, Rng& r
     int sx = s % A.sqrt_spp, sy = s / A.sqrt_spp;
     rng.sample = (unsigned)s;
     int j = global_row(A, L.lrow);
-    double r1 = (sx + rng_u(rng, 0, 0)) / A.sqrt_spp;
-    double r2 = (sy + rng_u(rng, 0, 1)) / A.sqrt_spp;
+    double r1 = (sx + (A.no_jitter ? 0.0 : rng_u(rng, 0, 0))) / A.sqrt_spp;
+    double r2 = (sy + (A.no_jitter ? 0.0 : rng_u(rng, 0, 1))) / A.sqrt_spp;
     double u = 1.0 - ((double)L.px + r1) / (A.W - 1);
     double v = ((double)j + r2) / (A.H - 1);
     D3 origin, dir;

@@ -9,7 +9,12 @@
 //   Sphere / Triangle / Cylinder::intersect  grazing rays, origins inside, d.axis = 0 (cap division by zero);
 //   Scene::intersect with a BVH on the same adversarial rays (gate boxes, tie rule);
 //   refract / fresnel / fresnelReflectance / reflect  incl. total internal reflection and the flip recursion;
-//   toneMap  all four operators.
+//   toneMap  all four operators;
+//   traceRayPath / estimateDirectLight  (private members: this driver, and only it, includes RayTracer.h with
+//     `private` spelled `public`; the reference's own translation units are compiled unmodified) on a scene of mirrors
+//     and glass under a point light, recursion depth <= 3: no Russian roulette, no hemisphere sample, no area-light
+//     sample -- fully deterministic (RayTracer.cpp:506-637), total internal reflection through the NaN of :572 included;
+//   getUV of the three classes and Material::getTextureColor at texel boundaries.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -19,8 +24,12 @@
 #include <vector>
 
 #include "BoundingBox.h"
+#include "Camera.h"
 #include "Cylinder.h"
+#include "PointLight.h"
+#define private public  // (this driver only: traceRayPath and estimateDirectLight are private members)
 #include "RayTracer.h"
+#undef private
 #include "Scene.h"
 #include "Sphere.h"
 #include "Triangle.h"
@@ -267,6 +276,119 @@ int main(int argc, char** argv) {
         }
         emit("tonemap_in", in, 3);
         emit("tonemap_out", out, 12);
+    }
+    // ---- traceRayPath / estimateDirectLight, deterministic part (src/RayTracer.cpp:506-637) -------------------
+    // The scene is emitted as data (one row per primitive: type, material, 12 geometry values as rt_scene_desc takes them)
+    // so that the tests rebuild it without a scene file.
+    {
+        const Vector3 bgc(0.53, 0.8, 0.92);
+        Scene scene(bgc);
+        struct M { double ks, kd; int e; bool refl; double r; bool refr; double ior; Vector3 dc, sc; };
+        const M mats[5] = {{0.1, 0.9, 20, false, 1.0, true, 1.5, Vector3(0.8, 0.5, 0.5), Vector3(1, 1, 1)},    // glass
+                           {0.3, 0.6, 10, true, 0.8, false, 1.0, Vector3(0.5, 0.5, 0.8), Vector3(1, 1, 1)},   // mirror
+                           {0.2, 0.7, 5, true, 0.6, true, 1.3, Vector3(0.5, 0.8, 0.5), Vector3(1, 0.9, 0.8)}, // both flags: the mirror branch wins (:543)
+                           {0.1, 0.9, 20, false, 1.0, true, 2.4, Vector3(0.9, 0.9, 0.9), Vector3(1, 1, 1)},   // dense glass: total internal reflection
+                           {0.4, 0.5, 30, true, 1.0, false, 1.0, Vector3(0.7, 0.7, 0.3), Vector3(1, 1, 1)}};  // floor mirror
+        auto mat_of = [&](int k) { const M& m = mats[k]; return Material(m.ks, m.kd, m.e, m.refl, m.r, m.refr, m.ior, m.dc, m.sc); };
+        std::vector<double> prims, matrows;
+        for (const M& m : mats) {
+            const double row[13] = {m.ks, m.kd, (double)m.e, m.refl ? 1.0 : 0.0, m.r, m.refr ? 1.0 : 0.0, m.ior, m.dc.x, m.dc.y, m.dc.z, m.sc.x, m.sc.y, m.sc.z};
+            matrows.insert(matrows.end(), row, row + 13);
+        }
+        auto add_sphere = [&](Vector3 c, double r, int m) {
+            scene.addObject(std::make_shared<Sphere>(c, r, mat_of(m)));
+            const double row[14] = {0, (double)m, c.x, c.y, c.z, r, 0, 0, 0, 0, 0, 0, 0, 0};
+            prims.insert(prims.end(), row, row + 14);
+        };
+        auto add_tri = [&](Vector3 a, Vector3 b, Vector3 c, int m) {
+            scene.addObject(std::make_shared<Triangle>(a, b, c, mat_of(m)));
+            const double row[14] = {1, (double)m, a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, 0, 0, 0};
+            prims.insert(prims.end(), row, row + 14);
+        };
+        auto add_cyl = [&](Vector3 base, Vector3 axis, double r, double h, int m) {  // constructor arguments (the constructor normalizes the axis)
+            scene.addObject(std::make_shared<Cylinder>(base, axis, r, h, mat_of(m)));
+            const double row[14] = {2, (double)m, base.x, base.y, base.z, axis.x, axis.y, axis.z, r, h, 0, 0, 0, 0};
+            prims.insert(prims.end(), row, row + 14);
+        };
+        add_sphere(Vector3(-0.35, -0.2, 1.0), 0.3, 0);
+        add_sphere(Vector3(0.45, 0.1, 1.6), 0.35, 1);
+        add_sphere(Vector3(-0.9, 0.0, 1.8), 0.25, 3);
+        add_cyl(Vector3(0.3, -0.5, 0.8), Vector3(0, 1, 0), 0.2, 0.5, 2);
+        add_cyl(Vector3(-0.2, 0.3, 1.9), Vector3(1, 0.5, 0.2), 0.15, 0.6, 0);
+        add_tri(Vector3(-2, -0.5, 3), Vector3(2, -0.5, 3), Vector3(2, -0.5, -1), 4);
+        add_tri(Vector3(-2, -0.5, -1), Vector3(-2, -0.5, 3), Vector3(2, -0.5, -1), 4);
+        add_tri(Vector3(-1.5, -0.5, 2.6), Vector3(1.5, -0.5, 2.6), Vector3(0, 1.8, 2.8), 1);
+        const Vector3 lpos(0.5, 2.5, -0.5), lint(1.2, 1.1, 0.9);
+        scene.addLight(std::make_shared<PointLight>(lpos, lint));
+        const int W = 48, H = 32, max_depth = 4;  // depths 0 .. 3: Russian roulette starts beyond (:530)
+        const Vector3 cpos(-2, 1, 0), clook(0.0, -0.1, 1.0), cup(0, 1, 0);
+        const double fov = 45.0, aspect = double(W) / H, focus = 2.0;
+        for (int bvh = 0; bvh < 2; ++bvh) {
+            if (bvh) scene.buildBVH();
+            Camera camera(cpos, clook, cup, fov, aspect, 0.0, focus);
+            RayTracer tracer(&scene, &camera, W, H);
+            tracer.setMaxDepth(max_depth);
+            tracer.setRenderMode(RayTracer::PATH_TRACE);
+            tracer.setLightSample(4);
+            std::vector<double> out, direct;
+            for (int j = 0; j < H; ++j)
+                for (int i = 0; i < W; ++i) {
+                    const double u = 1.0 - double(i) / (W - 1), v = double(j) / (H - 1);  // render()'s rays (:217-218)
+                    Ray ray = camera.getRay(u, v);
+                    push3(out, tracer.traceRayPath(ray, 0));
+                    HitRecord h;
+                    const bool hit = scene.intersect(ray, h);
+                    direct.push_back(hit ? 1.0 : 0.0);
+                    push3(direct, hit ? tracer.estimateDirectLight(h, -ray.direction.normalize()) : Vector3(0, 0, 0));
+                }
+            emit(bvh ? "pt_trace_bvh_out" : "pt_trace_linear_out", out, 3);
+            emit(bvh ? "pt_direct_bvh_out" : "pt_direct_linear_out", direct, 4);
+        }
+        emit("pt_prims", prims, 14);
+        emit("pt_materials", matrows, 13);
+        const double setup[20] = {(double)W, (double)H, (double)max_depth, fov, focus, cpos.x, cpos.y, cpos.z, clook.x, clook.y, clook.z,
+                                  lpos.x, lpos.y, lpos.z, lint.x, lint.y, lint.z, bgc.x, bgc.y, bgc.z};
+        emit("pt_setup", std::vector<double>(setup, setup + 20), 20);
+    }
+
+    // ---- getUV (src/Sphere.cpp:50-57, src/Triangle.cpp:15-39, src/Cylinder.cpp:109-129), getTextureColor (src/Material.cpp:69-86) ----
+    {
+        const Intersectable* prims[5] = {&sphere, &triangle, &cyl_y, &cyl_x, &cyl_d};
+        const char* names[5] = {"uv_sphere", "uv_triangle", "uv_cylinder_y", "uv_cylinder_x", "uv_cylinder_d"};
+        for (int p = 0; p < 5; ++p) {
+            std::vector<double> rows;
+            Lcg gu(4242 + p);
+            int found = 0;
+            for (int k = 0; k < 200000 && found < 600; ++k) {
+                Ray ray(Vector3(gu.range(-4, 4), gu.range(-4, 4), gu.range(-3, 0.5)), Vector3(gu.range(-1, 1), gu.range(-1, 1), gu.range(0.2, 1)));
+                HitRecord h;
+                if (!prims[p]->intersect(ray, h) || !h.getUV) continue;
+                double u = 0, v = 0;
+                h.getUV(h.point, u, v);
+                push3(rows, h.point);
+                rows.push_back(u);
+                rows.push_back(v);
+                ++found;
+            }
+            emit(names[p], rows, 5);
+        }
+        Material textured(0.5, 0.5, 10, false, 0.0, false, 1.0, Vector3(0.1, 0.2, 0.3), Vector3(1, 1, 1), true, "texture/checkerboard.ppm");
+        std::vector<double> rows;
+        Lcg gt(99);
+        const int TW = textured.textureWidth, TH = textured.textureHeight;
+        for (int k = 0; k < 3000; ++k) {
+            double u = gt.range(-1.5, 2.5), v = gt.range(-1.5, 2.5);
+            if (k % 3 == 0 && TW > 0) u = double(gt.pick(TW + 1)) / TW + (k % 2 ? 1e-17 : -1e-17) * (k % 5);   // texel boundaries
+            if (k % 4 == 0 && TH > 0) v = 1.0 - double(gt.pick(TH + 1)) / TH;
+            if (k == 1) { u = 0.0; v = 0.0; }
+            if (k == 2) { u = 1.0; v = 1.0; }
+            const Vector3 c = textured.getTextureColor(u, v);
+            const double row[5] = {u, v, c.x, c.y, c.z};
+            rows.insert(rows.end(), row, row + 5);
+        }
+        emit("texture_checkerboard", rows, 5);
+        const double dims[2] = {(double)TW, (double)TH};
+        emit("texture_checkerboard_size", std::vector<double>(dims, dims + 2), 2);
     }
     std::fclose(g_out);
     return 0;

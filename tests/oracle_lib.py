@@ -37,6 +37,10 @@ def load():
         lib.oracle_max_threads.restype = C.c_int
         lib.oracle_optics.restype = None
         lib.oracle_optics.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
+        lib.oracle_direct_light.restype = C.c_int
+        lib.oracle_direct_light.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_uv_texture.restype = C.c_int
+        lib.oracle_uv_texture.argtypes = [C.POINTER(capi.SceneDesc), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -93,3 +97,23 @@ def box_hit(box_lo_hi, origin, direction):
     o = np.ascontiguousarray(origin, dtype=np.float64)
     d = np.ascontiguousarray(direction, dtype=np.float64)
     return bool(load().oracle_box_hit(b.ctypes.data, o.ctypes.data, d.ctypes.data))
+
+
+def direct_light(desc, params, origins, dirs):
+    """estimateDirectLight at the closest hits of the rays: [n, 4] = (hit, direct xyz)."""
+    o = np.ascontiguousarray(origins, dtype=np.float64)
+    d = np.ascontiguousarray(dirs, dtype=np.float64)
+    out = np.zeros((o.shape[0], 4), dtype=np.float64)
+    assert load().oracle_direct_light(C.byref(desc), C.byref(params), o.shape[0], o.ctypes.data, d.ctypes.data, out.ctypes.data) == 0
+    return out
+
+
+def uv_texture(desc, prim, points=None, uv=None):
+    """getUV + getTextureColor: [n, 5] = (u, v, r, g, b); uv given: the texture lookup only."""
+    prim = np.ascontiguousarray(prim, dtype=np.int32)
+    pts = np.ascontiguousarray(points, dtype=np.float64) if points is not None else None
+    uvs = np.ascontiguousarray(uv, dtype=np.float64) if uv is not None else None
+    out = np.zeros((prim.shape[0], 5), dtype=np.float64)
+    assert load().oracle_uv_texture(C.byref(desc), prim.shape[0], prim.ctypes.data, pts.ctypes.data if pts is not None else None,
+                                    uvs.ctypes.data if uvs is not None else None, out.ctypes.data) == 0
+    return out

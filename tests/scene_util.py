@@ -22,7 +22,8 @@ class SyntheticScene:
     """Owns numpy arrays and exposes them as a capi.SceneDesc (keeps the arrays alive)."""
 
     def __init__(self, prim_type, prim_geom, materials=None, lights=None, background=(0.1, 0.2, 0.3), use_bvh=1,
-                 prim_material=None):
+                 prim_material=None, textures=None):
+        """textures: list of uint8 arrays [h, w, 3] (row 0 first, as Material::loadTexture keeps them)."""
         n = len(prim_type)
         self.prim_type = np.ascontiguousarray(prim_type, dtype=np.int32)
         self.prim_geom = np.ascontiguousarray(prim_geom, dtype=np.float64).reshape(n, capi.RT_GEOM_STRIDE)
@@ -39,6 +40,14 @@ class SyntheticScene:
         d.prim_geom = self.prim_geom.ctypes.data_as(C.POINTER(C.c_double))
         d.materials = C.cast(self.materials, C.POINTER(capi.Material))
         d.textures = None
+        self.texels = [np.ascontiguousarray(t, dtype=np.uint8) for t in (textures or [])]
+        if self.texels:
+            self.textures = (capi.Texture * len(self.texels))()
+            for k, t in enumerate(self.texels):
+                self.textures[k].width, self.textures[k].height = t.shape[1], t.shape[0]
+                self.textures[k].rgb = t.ctypes.data_as(C.POINTER(C.c_uint8))
+            d.textures = C.cast(self.textures, C.POINTER(capi.Texture))
+            d.n_textures = len(self.texels)
         d.lights = C.cast(self.lights, C.POINTER(capi.Light))
         d.background = capi.d3(*background)
         d.use_bvh = use_bvh
@@ -118,3 +127,23 @@ def make_params(width, height, mode=capi.RT_MODE_PHONG, max_depth=5, pixel_sampl
     p.band_rows, p.band_rank, p.band_world = 8, 0, 1
     p.sample_begin, p.sample_end = 0, 0
     return p
+
+
+def load_p6(path):
+    """A binary PPM as Material::loadTexture reads it (/root/reference/src/Material.cpp:17-67): uint8 [h, w, 3]."""
+    raw = open(path, "rb").read()
+    tokens, pos = [], 0
+    while len(tokens) < 4:
+        while raw[pos:pos + 1].isspace():
+            pos += 1
+        if raw[pos:pos + 1] == b"#":
+            pos = raw.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not raw[end:end + 1].isspace():
+            end += 1
+        tokens.append(raw[pos:end])
+        pos = end
+    assert tokens[0] == b"P6" and tokens[3] == b"255"
+    w, h = int(tokens[1]), int(tokens[2])
+    return np.frombuffer(raw, dtype=np.uint8, count=w * h * 3, offset=pos + 1).reshape(h, w, 3).copy()

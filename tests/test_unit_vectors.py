@@ -58,3 +58,55 @@ def test_optics_are_the_references(V):
 
 def test_tone_maps_are_the_references(V):
     assert np.array_equal(oracle_lib.tonemap(V["tonemap_in"]), V["tonemap_out"], equal_nan=True)
+
+
+# ---- the deterministic half of the path tracer (src/RayTracer.cpp:506-637), getUV, getTextureColor -----------------------
+
+def test_path_fixture_covers_the_branches(V):
+    out = V["pt_trace_bvh_out"]
+    assert np.isfinite(out).all() and (out >= 0).all()
+    bg = V["pt_setup"][0][17:20]
+    sky = (out == bg).all(axis=1)
+    assert 0.05 < sky.mean() < 0.9                               # rays that leave at once, and rays that do not
+    assert np.array_equal(V["pt_trace_bvh_out"], V["pt_trace_linear_out"])  # (no equal-t ties in this scene: both tie rules agree)
+    d = V["pt_direct_bvh_out"]
+    assert (d[:, 0] > 0).mean() > 0.3 and (d[d[:, 0] > 0, 1:] > 0).any(axis=1).mean() > 0.3  # lit and shadowed hits
+
+
+@pytest.mark.parametrize("bvh", [0, 1])
+def test_trace_ray_path_is_the_references(V, bvh):
+    """traceRayPath(ray, 0) on render()'s camera rays over mirrors, glass (both branches traced, total internal reflection
+    through the NaN of :572) and a point light, maxDepth 4: bit for bit."""
+    scene, cam, P = uv.pt_scene(V, bvh)
+    _, _, cnt, acc = oracle_lib.render(scene.desc, cam, P, want_hit=False, want_accum=True)
+    want = V["pt_trace_bvh_out" if bvh else "pt_trace_linear_out"].reshape(P.height, P.width, 3)
+    assert np.array_equal(acc, want)
+    assert cnt["rays"] > 3 * P.width * P.height
+
+
+@pytest.mark.parametrize("bvh", [0, 1])
+def test_estimate_direct_light_point_branch_is_the_references(V, bvh):
+    """estimateDirectLight at the primary hits, view = -ray.direction.normalize(): the (e + 2) / (2 pi) normalisation, the
+    unflipped normal, shadow test t < distance (:602-637)."""
+    scene, cam, P = uv.pt_scene(V, bvh)
+    o, d = uv.camera_rays(cam, P.width, P.height)
+    got = oracle_lib.direct_light(scene.desc, P, o, d)
+    want = V["pt_direct_bvh_out" if bvh else "pt_direct_linear_out"]
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert np.array_equal(got[:, 1:], want[:, 1:])
+
+
+@pytest.mark.parametrize("k,name", list(enumerate(uv.SCENE_ORDER)))
+def test_get_uv_is_the_references(V, k, name):
+    rows = V["uv_" + name]
+    got = oracle_lib.uv_texture(uv.textured_five_prim_scene().desc, np.full(len(rows), k), points=rows[:, 0:3])
+    assert np.array_equal(got[:, 0:2], rows[:, 3:5])   # same libm: atan2 / acos bit for bit
+
+
+def test_get_texture_color_is_the_references(V):
+    rows = V["texture_checkerboard"]
+    scene = uv.textured_five_prim_scene()
+    assert [scene.texels[0].shape[1], scene.texels[0].shape[0]] == list(V["texture_checkerboard_size"][0])
+    got = oracle_lib.uv_texture(scene.desc, np.zeros(len(rows), dtype=np.int32), uv=rows[:, 0:2])
+    assert np.array_equal(got[:, 2:5], rows[:, 2:5])
+    assert len(np.unique(rows[:, 2:5], axis=0)) >= 2     # (both colours of the board)
