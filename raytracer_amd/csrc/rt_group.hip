@@ -9,18 +9,29 @@
 //                      frame, pitch = world x band) assembles the frame on the first device over xGMI.  What
 //                      travels is the PPM payload (bytes) when the caller asks for bytes: an eighth of the fp64 frame.
 //   path trace         strata ranges (rt_params.sample_begin / sample_end): every member accumulates the radiance
-//                      sums of its strata for the whole frame, the sums are copied to the first device and added in
-//                      member order BEFORE the non-linear stages (/ pixelSamples, tone map, exposure, gamma, clamp:
-//                      RayTracer.cpp:301-315), which then run once.
-// No host thread per GPU is needed: every launch and copy is asynchronous on its member's stream (except the first
-// frame of a setup, which sizes each member's node store synchronously); the first device's stream waits for the
-// members' events, the caller for that stream.  One process per GPU with RCCL (raytracer_amd/dist.py, bench.py) is
-// the other way to run the same partition; both produce the same frame.
+//                      sums of its strata for the whole frame on its own GPU.  The sums are then combined as a
+//                      reduce-scatter by peer reads: member j owns pixels [n j / N, n (j + 1) / N), reads that slice of
+//                      every member's sums, adds them in member order BEFORE the non-linear stages (/ pixelSamples,
+//                      tone map, exposure, gamma, clamp: RayTracer.cpp:301-315), runs those stages (and the byte
+//                      conversion) on its slice and writes the finished slice into the frame on the first device.
+//                      Every GPU reads (N-1)/N of a frame and the first device receives (N-1)/N of a finished frame,
+//                      whatever N is; the order of the additions, and so the frame, does not depend on N's timing.
+// Every launch and copy is asynchronous on its member's stream; the first device's stream waits for the members'
+// events, the caller for that stream.  The exception is the first frame of a setup, in which each context sizes its node
+// store and waits for its own GPU (blockwave_host.inc): for that frame the members are driven by one host thread each,
+// so the sizing frames of N GPUs run side by side instead of one after the other.  One process per GPU with RCCL
+// (raytracer_amd/dist.py, bench.py) is the other way to run the same partition; both produce the same frame.
+//
+// Not measured on this project's hardware: the build box has one GPU, so the tests name device 0 several times
+// (tests/test_gpu_group.py) -- separate contexts, streams and buffers, the same partition, copies and reduction, but no
+// byte crosses xGMI.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_internal.hpp"
@@ -38,22 +49,37 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) group_add_kernel(double* dst, const double* src, long long n) {
+constexpr int kMaxMembers = 64;
+
+struct Sources {
+    const double* p[kMaxMembers];
+};
+
+// dst[i] = ((src0[begin + i] + src1[begin + i]) + src2[begin + i]) + ...: one slice of the members' radiance sums, the
+// sources read where they lie (peer memory for all but one of them)
+__global__ void __launch_bounds__(256) group_reduce_kernel(double* dst, Sources src, int world, long long begin, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = dst[i] + src[i];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double s = src.p[0][begin + i];
+        for (int k = 1; k < world; ++k) s = s + src.p[k][begin + i];
+        dst[i] = s;
+    }
 }
 
 struct Member {
     int device = 0;
     rt_context* ctx = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;         // this member's part of the frame has arrived on the first device
+    hipEvent_t accumulated = nullptr;  // path trace: this member's radiance sums are complete
     void* out = nullptr;      // this member's compact bands (bytes or doubles) / its radiance sums
     size_t out_bytes = 0;
     int* hit = nullptr;       // compact primary-hit ids
     size_t hit_bytes = 0;
-    void* staged = nullptr;   // on the first device: a copy of another member's radiance sums
-    size_t staged_bytes = 0;
+    void* slice = nullptr;    // path trace: the reduced (then resolved) slice this member owns
+    size_t slice_bytes = 0;
+    unsigned char* slice_u8 = nullptr;
+    size_t slice_u8_bytes = 0;
     int64_t rows = 0;
 };
 
@@ -77,6 +103,7 @@ struct rt_group {
     std::vector<Member> m;
     rt_params params;
     bool have_params = false;
+    bool fresh = true;      // no frame rendered since the setup changed: the members' contexts will size their node stores
     void* frame = nullptr;  // on the first device: the assembled frame (bytes or doubles)
     size_t frame_bytes = 0;
     unsigned char* frame_u8 = nullptr;  // path trace: the quantized frame
@@ -110,6 +137,75 @@ int scatter_bands(rt_group* g, int k, const void* src, void* frame, size_t elem)
     return RT_OK;
 }
 
+// Member k's own work for one frame, everything on its stream: render (bands or strata), hand the bands over.
+int render_member(rt_group* g, int k, bool want_u8, bool want_hit) {
+    const rt_params& p = g->params;
+    const bool pt = p.mode == RT_MODE_PATHTRACE;
+    const size_t n_px = (size_t)p.width * p.height;
+    const size_t elem = (pt || !want_u8) ? 3 * sizeof(double) : 3;
+    Member& me = g->m[k];
+    if (pt) {
+        // member 0's sums lie in the frame buffer itself (every slice of it is read by the slice's owner before that
+        // owner overwrites it, on one stream), the others' in a buffer of their own
+        if (k > 0) RT_TRY(ensure(&me.out, &me.out_bytes, n_px * elem, me.device));
+        RT_TRY(rt_pathtrace_accumulate_device(me.ctx, me.stream, k == 0 ? (double*)g->frame : (double*)me.out));
+        HIP_TRY(hipSetDevice(me.device));
+        HIP_TRY(hipEventRecord(me.accumulated, me.stream));
+        return RT_OK;
+    }
+    const size_t mine_px = (size_t)me.rows * p.width;
+    RT_TRY(ensure(&me.out, &me.out_bytes, std::max<size_t>(mine_px, 1) * elem, me.device));
+    if (want_hit) {
+        RT_TRY(ensure((void**)&me.hit, &me.hit_bytes, std::max<size_t>(mine_px, 1) * sizeof(int), me.device));
+        HIP_TRY(hipSetDevice(me.device));
+        HIP_TRY(hipMemsetAsync(me.hit, 0xFF, std::max<size_t>(mine_px, 1) * sizeof(int), me.stream));
+    }
+    if (mine_px > 0) {
+        if (want_u8) RT_TRY(rt_render_device_u8(me.ctx, me.stream, (uint8_t*)me.out, nullptr, want_hit ? me.hit : nullptr));
+        else RT_TRY(rt_render_device(me.ctx, me.stream, (double*)me.out, want_hit ? me.hit : nullptr));
+    }
+    RT_TRY(scatter_bands(g, k, me.out, g->frame, elem));
+    if (want_hit) RT_TRY(scatter_bands(g, k, me.hit, g->frame_hit, sizeof(int)));
+    HIP_TRY(hipSetDevice(me.device));
+    HIP_TRY(hipEventRecord(me.done, me.stream));
+    return RT_OK;
+}
+
+// Path trace, after every member has been launched: member j reduces, resolves and delivers the slice it owns.
+int combine_slices(rt_group* g, bool want_u8) {
+    const rt_params& p = g->params;
+    const int world = (int)g->m.size();
+    const long long n_px = (long long)p.width * p.height;
+    Sources src;
+    std::memset(&src, 0, sizeof src);
+    for (int k = 0; k < world; ++k) src.p[k] = k == 0 ? (const double*)g->frame : (const double*)g->m[k].out;
+    for (int j = 0; j < world; ++j) {
+        Member& me = g->m[j];
+        const long long lo = n_px * j / world, hi = n_px * (j + 1) / world, mine = hi - lo;
+        HIP_TRY(hipSetDevice(me.device));
+        if (mine > 0) {
+            RT_TRY(ensure(&me.slice, &me.slice_bytes, (size_t)mine * 3 * sizeof(double), me.device));
+            if (want_u8) RT_TRY(ensure((void**)&me.slice_u8, &me.slice_u8_bytes, (size_t)mine * 3, me.device));
+            HIP_TRY(hipSetDevice(me.device));
+            for (int k = 0; k < world; ++k)
+                if (k != j) HIP_TRY(hipStreamWaitEvent(me.stream, g->m[k].accumulated, 0));
+            const long long n = mine * 3;
+            const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+            hipLaunchKernelGGL(group_reduce_kernel, dim3(grid), dim3(256), 0, me.stream, (double*)me.slice, src, world, lo * 3, n);
+            HIP_TRY(hipGetLastError());
+            RT_TRY(rt_pathtrace_resolve_device(me.ctx, me.stream, (double*)me.slice, (int64_t)mine));
+            if (want_u8) {
+                RT_TRY(rt_quantize_device(me.ctx, me.stream, (const double*)me.slice, (int64_t)n, me.slice_u8));
+                HIP_TRY(hipMemcpyAsync(g->frame_u8 + lo * 3, me.slice_u8, (size_t)n, hipMemcpyDeviceToDevice, me.stream));
+            } else {
+                HIP_TRY(hipMemcpyAsync((double*)g->frame + lo * 3, me.slice, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, me.stream));
+            }
+        }
+        HIP_TRY(hipEventRecord(me.done, me.stream));
+    }
+    return RT_OK;
+}
+
 int render_frame(rt_group* g, bool want_u8, bool want_hit) {
     if (!g->have_params) return rt::set_error(RT_ERR_STATE, "rt_group: params not set");
     const rt_params& p = g->params;
@@ -121,49 +217,29 @@ int render_frame(rt_group* g, bool want_u8, bool want_hit) {
     RT_TRY(ensure(&g->frame, &g->frame_bytes, n_px * elem, first.device));
     if (want_hit) RT_TRY(ensure((void**)&g->frame_hit, &g->frame_hit_bytes, n_px * sizeof(int), first.device));
     if (pt && want_u8) RT_TRY(ensure((void**)&g->frame_u8, &g->frame_u8_bytes, n_px * 3, first.device));
-    for (int k = 0; k < world; ++k) {
-        Member& me = g->m[k];
-        if (pt) {
-            // member 0 accumulates straight into the frame; the others into their own buffer, then a copy on the first device
-            if (k > 0) {
-                RT_TRY(ensure(&me.out, &me.out_bytes, n_px * elem, me.device));
-                RT_TRY(ensure(&me.staged, &me.staged_bytes, n_px * elem, first.device));
-            }
-            double* target = k == 0 ? (double*)g->frame : (double*)me.out;
-            RT_TRY(rt_pathtrace_accumulate_device(me.ctx, me.stream, target));
-            if (k > 0) {
-                HIP_TRY(hipSetDevice(me.device));
-                HIP_TRY(hipMemcpyAsync(me.staged, me.out, n_px * elem, hipMemcpyDeviceToDevice, me.stream));
-            }
-        } else {
-            const size_t mine_px = (size_t)me.rows * p.width;
-            RT_TRY(ensure(&me.out, &me.out_bytes, std::max<size_t>(mine_px, 1) * elem, me.device));
-            if (want_hit) {
-                RT_TRY(ensure((void**)&me.hit, &me.hit_bytes, std::max<size_t>(mine_px, 1) * sizeof(int), me.device));
-                HIP_TRY(hipSetDevice(me.device));
-                HIP_TRY(hipMemsetAsync(me.hit, 0xFF, std::max<size_t>(mine_px, 1) * sizeof(int), me.stream));
-            }
-            if (mine_px > 0) {
-                if (want_u8) RT_TRY(rt_render_device_u8(me.ctx, me.stream, (uint8_t*)me.out, nullptr, want_hit ? me.hit : nullptr));
-                else RT_TRY(rt_render_device(me.ctx, me.stream, (double*)me.out, want_hit ? me.hit : nullptr));
-            }
-            RT_TRY(scatter_bands(g, k, me.out, g->frame, elem));
-            if (want_hit) RT_TRY(scatter_bands(g, k, me.hit, g->frame_hit, sizeof(int)));
-        }
-        HIP_TRY(hipSetDevice(me.device));
-        HIP_TRY(hipEventRecord(me.done, me.stream));
+    if (g->fresh && world > 1) {
+        // the sizing frame of each context ends in a wait for its GPU: one host thread per member, so that the GPUs'
+        // sizing frames overlap (error text is per thread: carried back by hand)
+        std::vector<int> rcs((size_t)world, RT_OK);
+        std::vector<std::string> msgs((size_t)world);
+        auto run = [&](int k) {
+            rcs[(size_t)k] = render_member(g, k, want_u8, want_hit);
+            if (rcs[(size_t)k] != RT_OK) msgs[(size_t)k] = rt_last_error();
+        };
+        std::vector<std::thread> workers;
+        for (int k = 1; k < world; ++k) workers.emplace_back(run, k);
+        run(0);
+        for (std::thread& t : workers) t.join();
+        for (int k = 0; k < world; ++k)
+            if (rcs[(size_t)k] != RT_OK) return rt::set_error(rcs[(size_t)k], "%s", msgs[(size_t)k].c_str());
+    } else {
+        for (int k = 0; k < world; ++k) RT_TRY(render_member(g, k, want_u8, want_hit));
     }
+    g->fresh = false;
+    if (pt) RT_TRY(combine_slices(g, want_u8));
     // the first device's stream continues once every member has delivered
     HIP_TRY(hipSetDevice(first.device));
     for (int k = 1; k < world; ++k) HIP_TRY(hipStreamWaitEvent(first.stream, g->m[k].done, 0));
-    if (pt) {
-        const long long n = (long long)n_px * 3;
-        for (int k = 1; k < world; ++k)  // fixed order: the sum does not depend on who finished first
-            hipLaunchKernelGGL(group_add_kernel, dim3(2048), dim3(256), 0, first.stream, (double*)g->frame, (const double*)g->m[k].staged, n);
-        HIP_TRY(hipGetLastError());
-        RT_TRY(rt_pathtrace_resolve_device(first.ctx, first.stream, (double*)g->frame, (int64_t)n_px));
-        if (want_u8) RT_TRY(rt_quantize_device(first.ctx, first.stream, (const double*)g->frame, (int64_t)n, g->frame_u8));
-    }
     return RT_OK;
 }
 
@@ -178,8 +254,11 @@ int render_to_host(rt_group* g, void* host, bool want_u8, int32_t* hit_host) {
         if (rc == RT_OK) {
             HIP_TRY(hipSetDevice(g->m[0].device));
             HIP_TRY(hipStreamSynchronize(g->m[0].stream));
+        } else {  // a launch failed part-way: let whatever the other members were given finish before anything is reused
+            for (Member& me : g->m)
+                if (hipSetDevice(me.device) == hipSuccess) (void)hipStreamSynchronize(me.stream);
         }
-        for (Member& me : g->m) {  // (also drains the members after a failed launch)
+        for (Member& me : g->m) {
             rt_stats st;
             int s = rt_get_stats(me.ctx, &st);
             if (s == RT_ERR_LIMIT) again = true;
@@ -188,6 +267,7 @@ int render_to_host(rt_group* g, void* host, bool want_u8, int32_t* hit_host) {
         if (rc == RT_ERR_LIMIT) again = true;  // an earlier asynchronous frame's overflow, reported by a launch
         else if (rc != RT_OK) return rc;
         if (!again) break;
+        g->fresh = true;  // the member that overflowed sizes its store anew
         if (attempt >= 4) return rt::set_error(RT_ERR_LIMIT, "rt_group: the node store overflowed %d times in a row", attempt + 1);
     }
     HIP_TRY(hipSetDevice(g->m[0].device));
@@ -205,7 +285,7 @@ int render_to_host(rt_group* g, void* host, bool want_u8, int32_t* hit_host) {
 extern "C" {
 
 int rt_group_create(rt_group** out, const int* devices, int n_devices) {
-    if (!out || !devices || n_devices < 1 || n_devices > 64) return rt::set_error(RT_ERR_INVALID, "rt_group_create: bad argument");
+    if (!out || !devices || n_devices < 1 || n_devices > kMaxMembers) return rt::set_error(RT_ERR_INVALID, "rt_group_create: bad argument");
     *out = nullptr;
     rt_group* g = new rt_group();
     g->m.resize((size_t)n_devices);
@@ -218,21 +298,23 @@ int rt_group_create(rt_group** out, const int* devices, int n_devices) {
         hipError_t e = hipSetDevice(me.device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&me.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&me.done, hipEventDisableTiming);
-        if (e == hipSuccess && me.device != devices[0]) {  // the member writes into the first device's memory
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&me.accumulated, hipEventDisableTiming);
+        // the member writes into the first device's memory and reads a slice of every other member's sums
+        for (int j = 0; j < n_devices && e == hipSuccess && rc == RT_OK; ++j) {
+            if (devices[j] == me.device) continue;
             int can = 0;
-            e = hipDeviceCanAccessPeer(&can, me.device, devices[0]);
-            if (e == hipSuccess && !can) {
-                rc = rt::set_error(RT_ERR_DEVICE, "rt_group_create: device %d cannot access device %d's memory", me.device, devices[0]);
-                break;
-            }
-            if (e == hipSuccess) {
-                e = hipDeviceEnablePeerAccess(devices[0], 0);
+            e = hipDeviceCanAccessPeer(&can, me.device, devices[j]);
+            if (e == hipSuccess && !can)
+                rc = rt::set_error(RT_ERR_DEVICE, "rt_group_create: device %d cannot access device %d's memory", me.device, devices[j]);
+            else if (e == hipSuccess) {
+                e = hipDeviceEnablePeerAccess(devices[j], 0);
                 if (e == hipErrorPeerAccessAlreadyEnabled) {
                     (void)hipGetLastError();
                     e = hipSuccess;
                 }
             }
         }
+        if (rc != RT_OK) break;
         if (e != hipSuccess) rc = rt::set_error(RT_ERR_DEVICE, "rt_group_create: device %d -> %s", me.device, hipGetErrorString(e));
     }
     if (rc != RT_OK) {
@@ -251,12 +333,14 @@ void rt_group_destroy(rt_group* g) {
         (void)hipDeviceSynchronize();
         (void)hipFree(me.out);
         (void)hipFree(me.hit);
+        (void)hipFree(me.slice);
+        (void)hipFree(me.slice_u8);
+        if (me.accumulated) (void)hipEventDestroy(me.accumulated);
         if (me.stream) (void)hipStreamDestroy(me.stream);
         if (me.done) (void)hipEventDestroy(me.done);
     }
     if (!g->m.empty() && g->m[0].ctx) {
         (void)hipSetDevice(g->m[0].device);
-        for (Member& me : g->m) (void)hipFree(me.staged);
         (void)hipFree(g->frame);
         (void)hipFree(g->frame_u8);
         (void)hipFree(g->frame_hit);
@@ -269,12 +353,14 @@ int rt_group_size(const rt_group* g) { return g ? (int)g->m.size() : rt::set_err
 
 int rt_group_upload_scene(rt_group* g, const rt_scene_desc* scene) {
     if (!g || !scene) return rt::set_error(RT_ERR_INVALID, "rt_group_upload_scene: null argument");
+    g->fresh = true;
     for (Member& me : g->m) RT_TRY(rt_upload_scene(me.ctx, scene));
     return RT_OK;
 }
 
 int rt_group_set_camera(rt_group* g, const rt_camera* cam) {
     if (!g || !cam) return rt::set_error(RT_ERR_INVALID, "rt_group_set_camera: null argument");
+    g->fresh = true;
     for (Member& me : g->m) RT_TRY(rt_set_camera(me.ctx, cam));
     return RT_OK;
 }
@@ -285,6 +371,7 @@ int rt_group_set_params(rt_group* g, const rt_params* p) {
         return rt::set_error(RT_ERR_INVALID, "rt_group_set_params: the group partitions the frame itself; pass whole-frame params "
                                              "(band_rank 0, band_world 1, sample_begin 0, sample_end 0)");
     const int world = (int)g->m.size();
+    g->fresh = true;
     for (int k = 0; k < world; ++k) {
         rt_params q = *p;
         if (p->mode == RT_MODE_PATHTRACE) {

@@ -104,3 +104,35 @@ def test_cli_splits_the_frame_over_the_listed_devices(ref_outputs, tmp_path):
                          timeout=120, env=dict(os.environ, RT_DEVICES="0,0,0,0"))
     assert res.returncode == 0, res.stderr
     assert hashlib.sha256(out.read_bytes()).hexdigest() == ref_outputs["clutter_500"]["sha256"]
+
+
+def test_first_frame_of_four_members_is_not_four_sizing_frames_in_a_row(ref_outputs, tmp_path):
+    """The first frame of a setup sizes every member's node store, and a sizing frame waits for its GPU: the group drives
+    the members from one host thread each for that frame.  First frame = the reference's bytes; and once buffers and code
+    objects exist (second setup of the same scene), a first frame takes less than twice a later one."""
+    import time
+    g = rt.Group([0] * 4)
+    try:
+        sf = scene_util.load("clutter_500", 1920, 1080)
+        small = scene_util.load("clutter_500")
+        g.load(small)
+        u8, _ = g.render_u8()  # the very first frame of the group
+        out = tmp_path / "g.ppm"
+        rt.write_ppm_u8(out, u8)
+        assert hashlib.sha256(out.read_bytes()).hexdigest() == ref_outputs["clutter_500"]["sha256"]
+        g.load(sf)
+        ref, _ = g.render_u8()
+        firsts, laters = [], []
+        for _ in range(3):
+            g.load(sf)  # new setup generation: every context sizes its store again
+            t0 = time.perf_counter()
+            a, _ = g.render_u8()
+            t1 = time.perf_counter()
+            b, _ = g.render_u8()
+            t2 = time.perf_counter()
+            assert np.array_equal(a, ref) and np.array_equal(b, ref)
+            firsts.append(t1 - t0); laters.append(t2 - t1)
+        print("first frames %s later frames %s (s)" % (firsts, laters))
+        assert min(firsts) < 2.0 * min(laters)
+    finally:
+        g.close()
