@@ -312,7 +312,8 @@ class Bench:
         ref_counts = self.reference_counts(sf, desc, P)
         r = rt.Renderer(self.local_rank)
         r.upload(desc); r.set_camera(sf.camera); r.set_params(P)
-        pipe = rtd.AccumulatorPipeline(self.world, H * W * 3, self.dev, depth=2)
+        pipe = rtd.AccumulatorPipeline(self.rank, self.world, H * W, self.dev, depth=2)
+        u8 = [torch.zeros(pipe.slice_px * 3, dtype=torch.uint8, device=self.dev) for _ in range(2)]
         stream = torch.cuda.current_stream().cuda_stream
         steps = max(args.pt_steps, 1)
 
@@ -324,9 +325,12 @@ class Bench:
             pipe.submit(k)
 
         def finish(k):
-            out = pipe.complete(k)
-            if self.rank == 0:
-                r.resolve_device(out.data_ptr(), H * W, stream=stream)
+            # this rank's slice of the summed frame: / pixelSamples, tone map, gamma, clamp, PPM bytes; rank 0 gathers the bytes
+            def stages(sums, n_px):
+                r.resolve_device(sums.data_ptr(), n_px, stream=stream)
+                r.quantize_device(sums.data_ptr(), n_px * 3, u8[k % 2].data_ptr(), stream=stream)
+                return u8[k % 2]
+            pipe.complete(k, stages)
 
         def run(n, events=None):
             for k in range(n):

@@ -1,9 +1,9 @@
 """Partition of one frame over ranks and its recombination with torch.distributed.
 
 Whitted / binary: 8-row bands dealt round-robin (rt_params.band_*), disjoint outputs -> gather.
-Path trace: strata ranges (rt_params.sample_begin/sample_end), partial radiance sums -> reduce(SUM)
+Path trace: strata ranges (rt_params.sample_begin/sample_end), partial radiance sums -> reduce-scatter(SUM)
 BEFORE the non-linear stages (division by pixelSamples, tone map, exposure, gamma, clamp:
-/root/reference/src/RayTracer.cpp:301-315).  The same functions run over RCCL on GPUs (bench.py)
+/root/reference/src/RayTracer.cpp:301-315), which every rank applies to its slice -> gather.  The same functions run over RCCL on GPUs (bench.py)
 and over gloo on CPU tensors (tests/test_multiproc_gloo.py).
 """
 import torch
@@ -172,13 +172,30 @@ class FramePipeline:
 
 
 class AccumulatorPipeline:
-    """Path-trace passes of a multi-GPU job, pipelined the same way: pass k's partial radiance sums are
-    reduced (SUM) to rank 0 asynchronously while pass k+1 runs."""
+    """Path-trace passes of a multi-GPU job as SURVEY.md 8(e) lays them out: every rank accumulates the radiance sums
+    of its strata for the whole frame; pass k's sums are combined by a reduce-scatter (SUM) that leaves each rank with
+    the complete sums of ITS slice of the pixels (1/world of them, padded to equal slices), each rank applies the
+    non-linear stages to its slice (`finish`: / pixelSamples, tone map, exposure, gamma, clamp -- RayTracer.cpp:301-315
+    -- and, if the caller wants PPM bytes, the byte conversion), and the finished slices are gathered on rank 0.  The
+    reduce-scatter runs asynchronously while pass k + 1 is rendered.  Per GPU and pass (world - 1) / world of one fp64
+    frame crosses the links in the reduce-scatter and 1 / world of a finished frame in the gather, whatever world is.
 
-    def __init__(self, world, n_values, device, depth=2):
-        self.world, self.depth = world, depth
-        self.accum = [torch.empty(n_values, dtype=torch.float64, device=device) for _ in range(depth)]
+    target(k)            the [slice_px * world * 3] fp64 buffer pass k accumulates into (the renderer writes the
+                         leading n_pixels * 3 values; the padding stays 0)
+    submit(k)            call after pass k's accumulation was enqueued on the current stream
+    complete(k, finish)  finish(sums, n_px) -> tensor: `sums` is this rank's reduced slice ([slice_px * 3] fp64, to be
+                         resolved in place or into a tensor of any dtype with slice_px * 3 elements), n_px = slice_px.
+                         Returns the assembled frame ([n_pixels * 3], finish's dtype) on rank 0, None elsewhere.
+                         finish=None gathers the sums themselves."""
+
+    def __init__(self, rank, world, n_pixels, device, depth=2):
+        self.rank, self.world, self.depth, self.n_pixels = rank, world, depth, n_pixels
+        self.slice_px = (n_pixels + world - 1) // world
+        n = self.slice_px * world * 3
+        self.accum = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(depth)]
+        self.mine = [torch.zeros(self.slice_px * 3, dtype=torch.float64, device=device) for _ in range(depth)] if world > 1 else None
         self.pending = [None] * depth
+        self._recv = {}  # dtype -> per-slot receive buffers on rank 0
 
     def target(self, k):
         return self.accum[k % self.depth]
@@ -186,18 +203,31 @@ class AccumulatorPipeline:
     def submit(self, k):
         i = k % self.depth
         if self.world > 1:
-            self.pending[i] = dist.reduce(self.accum[i], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            self.pending[i] = dist.reduce_scatter_tensor(self.mine[i], self.accum[i], op=dist.ReduceOp.SUM, async_op=True)
 
-    def complete(self, k):
+    def complete(self, k, finish=None):
         i = k % self.depth
+        if self.world == 1:
+            out = finish(self.accum[i], self.slice_px) if finish else self.accum[i]
+            return out[: self.n_pixels * 3]
         work, self.pending[i] = self.pending[i], None
         if work is not None:
             work.wait()
-        return self.accum[i]
+        out = finish(self.mine[i], self.slice_px) if finish else self.mine[i]
+        assert out.numel() == self.slice_px * 3
+        recv = None
+        if self.rank == 0:
+            if out.dtype not in self._recv:
+                self._recv[out.dtype] = [torch.empty(self.world, self.slice_px * 3, dtype=out.dtype, device=out.device)
+                                         for _ in range(self.depth)]
+            recv = self._recv[out.dtype][i]
+        dist.gather(out.view(-1), [recv[q] for q in range(self.world)] if self.rank == 0 else None, dst=0)
+        return recv.view(-1)[: self.n_pixels * 3] if self.rank == 0 else None
 
 
 def reduce_accumulators(accum, world):
-    """Sum of the per-rank radiance accumulators on rank 0 (in place)."""
+    """Sum of the per-rank radiance accumulators on rank 0 (in place): the plain form, for callers that want the sums
+    themselves in one place (tests, single passes)."""
     if world > 1:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     return accum

@@ -70,17 +70,25 @@ def _worker(rank, world, port, q):
             ok4 = check4(k) and ok4
         if rank == 0:
             out["pipeline4_equal"] = ok4
-        ap = rtd.AccumulatorPipeline(world, 8, torch.device("cpu"))
+        # 7 pixels over 2 ranks: slices of 4 pixels, the last one padded; pass k's sums = (rank + 1 + k) * (1 + pixel value index)
+        ap = rtd.AccumulatorPipeline(rank, world, 7, torch.device("cpu"))
+        ramp = torch.arange(1, 22, dtype=torch.float64)
+        def expect(k, scale=1.0):
+            return (ramp * float(sum(r + 1 + k for r in range(world))) * scale).numpy()
+        ok = True
         for k in range(3):
-            ap.target(k).fill_(float(rank + 1 + k))
+            t = ap.target(k)
+            assert t.numel() == 24
+            t[:21] = ramp * float(rank + 1 + k)
             ap.submit(k)
             if k > 0:
                 got = ap.complete(k - 1)
                 if rank == 0:
-                    ok = ok and bool((got == float(sum(r + 1 + (k - 1) for r in range(world)))).all())
-        got = ap.complete(2)
+                    ok = ok and got.shape == (21,) and bool(np.array_equal(got.numpy(), expect(k - 1)))
+        # the last pass with a finish step of another dtype (the non-linear stages + byte conversion of bench.py)
+        got = ap.complete(2, finish=lambda sums, n_px: (sums * 0.5).to(torch.float32))
         if rank == 0:
-            out["accum_pipeline"] = ok and bool((got == float(sum(r + 1 + 2 for r in range(world)))).all())
+            out["accum_pipeline"] = ok and got.dtype == torch.float32 and bool(np.array_equal(got.numpy(), expect(2, 0.5).astype(np.float32)))
         # ---- path trace: strata ranges -> reduce -> resolve --------------------------------------
         pt = scene_util.load("pathtrace", 24, 16)
         Q = pt.params
