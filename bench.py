@@ -18,15 +18,22 @@ and prints them on ONE JSON line:
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) ONE frame is split over the ranks --
 row bands for Whitted, strata ranges for path tracing -- and recombined on rank 0's device through RCCL
-inside the timed region: a gather of the bands as PPM bytes / a reduce of the fp64 partial sums before
-the non-linear stages.  Total work is fixed, so "scaling" is "strong".
+inside the timed region: a gather of the bands as PPM bytes / a reduce-scatter of the fp64 partial sums
+before the non-linear stages, which each rank applies to its slice, and a gather of the finished slices
+(SURVEY.md 8(e)).  Total work is fixed, so "scaling" is "strong".  `python bench.py --gpus N` without
+WORLD_SIZE in the environment starts the N ranks itself (fresh children, before this process touches a
+GPU) and fails loudly when fewer than N GPUs are visible; `--mode group` times the one-process form
+(rt_group_render_u8 over devices 0..N-1) instead.
 
 `roofline` prices the render kernels against the fp64 VALU peak WITHOUT FMA credit (contraction is off
 for parity): algorithmic ops = 24 per box test + 33 per sphere + 62 per triangle + 150 per cylinder test
 (SURVEY.md 8(d)), counted on the REFERENCE's traversal order by one untimed frame with
-RT_TRAVERSAL=walk, divided by the kernels' duration (HIP events on the stream they run on).  What the
-production traversal really executes is reported beside it (`executed_*`, from one untimed frame of the
--DRT_FBVH_COUNTS=1 build in a child process).  `cpu_baseline` is the pinned fp64 CPU restatement
+RT_TRAVERSAL=walk, divided by the kernels' duration (HIP events on the stream they run on).  Beside
+`frac`: `frac_walked` (the same numerator without the tests of rays that are counted but never walked:
+shadow rays of refracting Whitted hits, of dark and clear path-traced hits), for the path tracer
+`frac_with_sampling` (plus a lower bound of the reference's per-light-sample arithmetic), and what the
+production traversal really executes (`executed_*`, from one untimed frame of the -DRT_FBVH_COUNTS=1
+build in a child process).  `cpu_baseline` is the pinned fp64 CPU restatement
 (oracle/) on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
@@ -377,7 +384,7 @@ class Bench:
                 # ... and with the per-sample arithmetic of the reference priced in (lower bound, see bench.py)
                 "frac_with_sampling": (alg_ops + sample_ops) / self.world / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
                 "sampling_ops_per_shadow_ray": 53.0,
-                "kernel": ("pq_kernel (one launch per 64 strata; every wave on its own: ray pass = 64 stacked rays or new roots -> closest "
+                "kernel": ("pq_kernel (one launch per 256 strata; every wave on its own: ray pass = 64 stacked rays or new roots -> closest "
                            "hit; hit pass = 64 hits -> class dark / clear / general, material branch, child rays; light pass = 4 hits x "
                            "16 samples; exact per-pixel sums added to the frame)") if os.environ.get("RT_PT_QUEUES", "1") != "0" else
                           "pt_kernel (per batch of 4 strata; per depth: trace, classify, light, shade; combine) + bw_accumulate_path_kernel",

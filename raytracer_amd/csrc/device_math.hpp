@@ -307,8 +307,9 @@ RT_DEV bool cylinder_t(const double* cy, D3 o, D3 dir, double& t_out, int& part_
 // 8 lanes), 0x140 = row_mirror (15 - lane within the row).
 template <int kCtrl>
 RT_DEV double dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xF, 0xF, false);
+    // (every lane has a source lane under these controls: no "old" value, which would cost a v_mov per half)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), kCtrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), kCtrl, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 

@@ -3,9 +3,9 @@
 #include "rt_device.hpp"
 
 namespace rt {
-const void* pq_kernel_ptr() {
+const void* pq_kernel_ptr(int shadow_rays_per_hit) {
     using Fn = void (*)(SceneView, RenderArgs, PqArgs);
-    static const Fn fn = pq_kernel<3>;
-    return (const void*)fn;
+    static const Fn s16 = pq_kernel<3, 16>, any = pq_kernel<3, 0>;
+    return (const void*)(shadow_rays_per_hit == 16 ? s16 : any);
 }
 }  // namespace rt
