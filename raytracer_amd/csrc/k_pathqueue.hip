@@ -3,9 +3,10 @@
 #include "rt_device.hpp"
 
 namespace rt {
-const void* pq_kernel_ptr(int shadow_rays_per_hit) {
+const void* pq_kernel_ptr(int shadow_rays_per_hit, int waves) {
     using Fn = void (*)(SceneView, RenderArgs, PqArgs);
-    static const Fn s16 = pq_kernel<3, 16>, any = pq_kernel<3, 0>;
-    return (const void*)(shadow_rays_per_hit == 16 ? s16 : any);
+    static const Fn tab[2][2] = {{pq_kernel<3, 0, kPqWavesFew>, pq_kernel<3, 0, kPqWavesMany>},
+                                 {pq_kernel<3, 16, kPqWavesFew>, pq_kernel<3, 16, kPqWavesMany>}};
+    return (const void*)tab[shadow_rays_per_hit == 16 ? 1 : 0][waves == kPqWavesMany ? 1 : 0];
 }
 }  // namespace rt

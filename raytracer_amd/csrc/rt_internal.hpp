@@ -62,6 +62,6 @@ const void* bw_kernel_ptr(bool path_trace, bool lds, int tv);
 const void* fw_kernel_ptr(bool path_trace, bool lds, int tv);
 const void* fw_roots_kernel_ptr(bool lds, int tv);
 const void* pt_kernel_ptr(bool lds, int tv);
-const void* pq_kernel_ptr(int shadow_rays_per_hit);  // (SceneView, RenderArgs, PqArgs): path trace out of per-wave queues, LDS-resident scenes, filter-BVH traversal
+const void* pq_kernel_ptr(int shadow_rays_per_hit, int waves);  // (SceneView, RenderArgs, PqArgs): path trace out of per-wave queues, LDS-resident scenes, filter-BVH traversal
 
 }  // namespace rt

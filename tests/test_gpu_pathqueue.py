@@ -48,7 +48,8 @@ def test_level_kernel_and_queue_kernel_agree():
 
 def test_frame_does_not_depend_on_how_roots_are_dealt(monkeypatch):
     """A pixel's terms are summed exactly (96-bit fixed point) and rounded once: job size, the golden-ratio dealing order,
-    the cost-ordered job table and the frame's repetition must not change a bit."""
+    the cost-ordered job table, the frame's repetition and the kernel's instantiation (12 or 16 waves per workgroup) must
+    not change a bit."""
     r = _make({})
     try:
         for name, w, h, spp, ls in CASES[:3]:
@@ -59,7 +60,7 @@ def test_frame_does_not_depend_on_how_roots_are_dealt(monkeypatch):
             again, _ = r.render(want_hit=False)  # (the second frame of a setup follows the first one's job costs)
             assert np.array_equal(ref, again)
             for env in ({"RT_PQ_JOB": "64"}, {"RT_PQ_JOB": "2048"}, {"RT_PQ_NO_INTERLEAVE": "1"}, {"RT_PQ_NO_ORDER": "1"},
-                        {"RT_PQ_MIN_PIECE": "8"}):
+                        {"RT_PQ_MIN_PIECE": "8"}, {"RT_PQ_WAVES": "12"}, {"RT_PQ_WAVES": "16"}):
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 for _ in range(2):
@@ -132,6 +133,35 @@ def test_exact_accumulator_arithmetic(renderer):
     for k in range(n):
         exact = trunc(a[k]) + trunc(b[k]) + trunc(3.0 * a[k]) + trunc(-b[k])
         assert got[k] == float(exact), (k, a[k], b[k], got[k], float(exact))  # float(Fraction) rounds to nearest-even
+
+
+def test_mid_sized_scene_takes_the_twelve_wave_kernel(renderer, monkeypatch):
+    """90 primitives: the image leaves 16 waves fewer than 168 accumulator slots each, so pq_kernel runs with 12 waves per
+    workgroup (and fewer slots than the tiny scenes get) -- oracle parity, and the level kernel agrees."""
+    from tests import oracle_lib
+    rng = np.random.default_rng(21)
+    types, geom = scene_util.random_prims(rng, 50, 30, 10, extent=3.0)
+    mats = [scene_util.default_material(), scene_util.default_material(reflective=1, reflectivity=0.8),
+            scene_util.default_material(refractive=1, ior=1.5)]
+    light = scene_util.area_light((0.0, 5.0, 0.0), (0, -1, 0), (1, 0, 0), (0, 0, 1), 1.5, 1.5)
+    syn = scene_util.SyntheticScene(types, geom, materials=mats, lights=[light], use_bvh=1, prim_material=rng.integers(0, 3, len(types)))
+    cam = scene_util.look_at((5, 3, -6), (0, 0, 0), aspect=1.5)
+    P = scene_util.make_params(96, 64, mode=rt.RT_MODE_PATHTRACE, max_depth=5, pixel_samples=4, light_samples=16)
+    renderer.upload(syn.desc); renderer.set_camera(cam); renderer.set_params(P)
+    rgb, _ = renderer.render(want_hit=False)
+    st = renderer.stats()
+    assert st.kernel_launches == 1  # (pq_kernel: one launch for the 4 strata; pt_kernel would also report 1 here, hence the next check)
+    orgb, _, cnt, _ = oracle_lib.render(syn.desc, cam, P, want_hit=False)
+    assert (np.abs(rgb - orgb).max(axis=2) > 1e-9).mean() <= 1e-3
+    assert abs(st.rays - cnt["rays"]) <= 1e-3 * cnt["rays"]
+    lv = _make({"RT_PT_QUEUES": "0"})
+    try:
+        lv.upload(syn.desc); lv.set_camera(cam); lv.set_params(P)
+        a, _ = lv.render(want_hit=False)
+        assert lv.stats().rays == st.rays
+        assert np.abs(a - rgb).max() < 1e-12 and not np.array_equal(a, rgb)
+    finally:
+        lv.close()
 
 
 def test_scene_too_large_for_the_queues_takes_the_level_kernel(renderer):
