@@ -180,3 +180,40 @@ def test_scene_too_large_for_the_queues_takes_the_level_kernel(renderer):
     assert st.scene_in_lds == 1
     orgb, _, cnt, _ = oracle_lib.render(syn.desc, cam, P, want_hit=False)
     assert (np.abs(rgb - orgb).max(axis=2) > 1e-9).mean() <= 1e-3
+
+
+def test_a_ray_stack_that_runs_out_hands_the_setup_to_the_level_kernel(monkeypatch):
+    """pq_kernel's stack bound excludes an overflow; RT_PQ_DEBUG_STACK makes the stacks too small on purpose.  The wave that
+    would write past its stack sets the flag instead, the blocking entry point discards the frame and renders it again --
+    with pt_kernel, which this context then keeps for the setup: the frame a RT_PT_QUEUES=0 context renders, bit for bit."""
+    sf, P = load("pathtrace", 120, 80, 16, 4)
+    lv = _make({"RT_PT_QUEUES": "0"})
+    monkeypatch.setenv("RT_PQ_DEBUG_STACK", "80")
+    r = _make({})
+    try:
+        lv.load(sf, P)
+        want, _ = lv.render(want_hit=False)
+        r.load(sf, P)
+        got, _ = r.render(want_hit=False)
+        assert np.array_equal(got, want)
+        assert r.stats().rays == lv.stats().rays
+        again, _ = r.render(want_hit=False)  # no second overflow: the queues are off for this context
+        assert np.array_equal(again, want)
+        # the asynchronous entry point reports instead of repeating: first call renders an invalid frame, the next one says so
+        r2 = _make({})
+        try:
+            import torch
+            r2.load(sf, P)
+            acc = torch.zeros(80 * 120 * 3, dtype=torch.float64, device="cuda")
+            stream = torch.cuda.current_stream().cuda_stream
+            r2.accumulate_device(acc.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            with pytest.raises(rt.RtError, match="overflowed"):
+                r2.accumulate_device(acc.data_ptr(), stream=stream)
+            r2.accumulate_device(acc.data_ptr(), stream=stream)  # pt_kernel now
+            torch.cuda.synchronize()
+            r2.stats()
+        finally:
+            r2.close()
+    finally:
+        lv.close(); r.close()
