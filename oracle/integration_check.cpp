@@ -4,13 +4,15 @@
 // reference's own headers (/root/reference/include) and links it with the reference's classes (its sources are
 // compiled where they lie, main renamed) and with libraytracer_amd.so.  It proves that the C-ABI in
 // include/raytracer_amd.h can be fed from the reference's objects at its seam (src/RayTracer.cpp:146-149) with
-// nothing but public members: the output goes to oracle/_ref/ (git-ignored, gpurun-ignored) and is never run
-// on the GPU box -- the reference does not travel.
+// nothing but public members, and -- run on a GPU -- that the frame it returns is the frame the reference's own render()
+// computes from the same objects.  The output goes to oracle/_ref/ (git-ignored and gpurun-ignored: nothing built from
+// the reference leaves the build container).
 //
 // render_on_gpu() is what a maintainer of the reference would call instead of rayTracer.render(out) /
 // rayTracer.renderPathTrace(out); the rest of main() stays as it is.
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -177,27 +179,85 @@ int render_on_gpu(const Scene& scene, const Camera& cam, int W, int H, RayTracer
 
 }  // namespace
 
-// A scene built from the reference's own classes, rendered through the binding, written by the reference's own
-// writer.  (Only linked in this container; it needs a gfx950 GPU to run.)
-int main(int argc, char** argv) {
-    const int W = 120, H = 80;
-    Scene scene(Vector3(0.2, 0.3, 0.4));
-    Material red(0.3, 0.7, 20, false, 0.0, false, 1.0, Vector3(0.8, 0.2, 0.2), Vector3(1, 1, 1));
-    scene.addObject(std::make_shared<Sphere>(Vector3(0, 0, 4), 1.0, red));
-    scene.addObject(std::make_shared<Triangle>(Vector3(-3, -1, 1), Vector3(3, -1, 1), Vector3(0, -1, 8), red));
-    scene.addObject(std::make_shared<Cylinder>(Vector3(1.5, -1, 4), Vector3(0, 1, 0), 0.4, 1.5, red));
-    scene.addLight(std::make_shared<PointLight>(Vector3(3, 5, 0), Vector3(1, 1, 1)));
-    scene.addLight(std::make_shared<AreaLight>(Vector3(0, 4, 4), Vector3(0, -1, 0), Vector3(1, 0, 0), Vector3(0, 0, 1), 1.0, 1.0,
-                                               Vector3(2, 2, 2)));
-    scene.buildBVH();
-    Camera camera(Vector3(0, 0, 0), Vector3(0, 0, 1), Vector3(0, 1, 0), 45.0, double(W) / H);
+// Scenes built from the reference's own classes, rendered twice: through the binding on the GPU (written by the
+// reference's own writer) and by the reference's own render() on the CPU, from the same objects.  The two P3 files must
+// be identical byte for byte.  Exit status 0 = all identical, 2 = a difference, 1 = the library failed.
+// (Linked in the build container; tests/test_gpu_integration_binary.py runs it wherever a gfx950 GPU and this binary are
+// both present, and is skipped elsewhere.)
+namespace {
+
+std::string slurp(const std::string& path) {
+    std::string out;
+    if (FILE* f = std::fopen(path.c_str(), "rb")) {
+        char buf[1 << 16];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+        std::fclose(f);
+    }
+    return out;
+}
+
+// one comparison; returns 0 / 1 / 2 as above
+int compare(const char* name, Scene& scene, Camera& camera, int W, int H, RayTracer::RenderMode mode, RayTracer::ToneMapping tm,
+            int maxDepth, double exposure, const std::string& dir) {
     std::vector<std::vector<Vector3>> buffer;
-    int rc = render_on_gpu(scene, camera, W, H, RayTracer::PHONG, RayTracer::NONE, 5, 16, 4, 1.0, buffer);
+    int rc = render_on_gpu(scene, camera, W, H, mode, tm, maxDepth, 16, 4, exposure, buffer);
     if (rc != RT_OK) {
-        std::cerr << "Error: " << rt_last_error() << std::endl;
+        std::cerr << name << ": " << rt_last_error() << std::endl;
         return 1;
     }
-    RayTracer writer(&scene, &camera, W, H);
-    writer.writeImageToPPM(argc > 1 ? argv[1] : "integration_check.ppm", buffer);
+    const std::string gpu_file = dir + "/" + name + "_gpu.ppm", ref_file = dir + "/" + name + "_ref.ppm";
+    RayTracer rayTracer(&scene, &camera, W, H);  // the reference's main(), src/RayTracer.cpp:127-147
+    rayTracer.setRenderMode(mode);
+    rayTracer.setMaxDepth(maxDepth);
+    rayTracer.setToneMap(tm);
+    rayTracer.setExposure(exposure);
+    rayTracer.writeImageToPPM(gpu_file, buffer);
+    rayTracer.render(ref_file);
+    const std::string a = slurp(gpu_file), b = slurp(ref_file);
+    if (a.empty() || a != b) {
+        size_t at = 0;
+        while (at < a.size() && at < b.size() && a[at] == b[at]) ++at;
+        std::cout << name << ": DIFFERENT (" << a.size() << " / " << b.size() << " bytes, first difference at byte " << at << ")" << std::endl;
+        return 2;
+    }
+    std::cout << name << ": identical (" << a.size() << " bytes)" << std::endl;
     return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const std::string dir = argc > 1 ? argv[1] : ".";
+    const int W = 120, H = 80;
+    int worst = 0;
+    auto keep = [&](int rc) { worst = rc == 1 || worst == 1 ? 1 : (rc > worst ? rc : worst); };
+    Material red(0.3, 0.7, 20, false, 0.0, false, 1.0, Vector3(0.8, 0.2, 0.2), Vector3(1, 1, 1));
+    Material mirror(0.5, 0.4, 50, true, 0.6, false, 1.0, Vector3(0.9, 0.9, 0.9), Vector3(1, 1, 1));
+    Material glass(0.2, 0.1, 80, false, 0.0, true, 1.5, Vector3(0.9, 0.9, 1.0), Vector3(1, 1, 1));
+    Material green(0.1, 0.9, 5, false, 0.0, false, 1.0, Vector3(0.2, 0.7, 0.3), Vector3(1, 1, 1));
+    Camera camera(Vector3(0, 0, 0), Vector3(0, 0, 1), Vector3(0, 1, 0), 45.0, double(W) / H);
+    {   // every primitive class, a point light, the BVH's tie rule
+        Scene scene(Vector3(0.2, 0.3, 0.4));
+        scene.addObject(std::make_shared<Sphere>(Vector3(0, 0, 4), 1.0, red));
+        scene.addObject(std::make_shared<Triangle>(Vector3(-3, -1, 1), Vector3(3, -1, 1), Vector3(0, -1, 8), green));
+        scene.addObject(std::make_shared<Cylinder>(Vector3(1.5, -1, 4), Vector3(0, 1, 0), 0.4, 1.5, red));
+        scene.addLight(std::make_shared<PointLight>(Vector3(3, 5, 0), Vector3(1, 1, 1)));
+        scene.buildBVH();
+        keep(compare("phong_bvh", scene, camera, W, H, RayTracer::PHONG, RayTracer::NONE, 5, 1.0, dir));
+        keep(compare("binary_bvh", scene, camera, W, H, RayTracer::BINARY, RayTracer::NONE, 5, 1.0, dir));
+    }
+    {   // mirror and glass bounces, two lights, no BVH (the linear scan's tie rule), a tone map
+        Scene scene(Vector3(0.25, 0.25, 0.3));
+        scene.addObject(std::make_shared<Sphere>(Vector3(-1.2, 0, 5), 1.0, mirror));
+        scene.addObject(std::make_shared<Sphere>(Vector3(1.0, -0.2, 3.5), 0.8, glass));
+        scene.addObject(std::make_shared<Cylinder>(Vector3(0.2, -1, 6), Vector3(0.3, 1, 0.1), 0.5, 2.0, red));
+        scene.addObject(std::make_shared<Triangle>(Vector3(-6, -1, 0), Vector3(6, -1, 0), Vector3(0, -1, 14), green));
+        scene.addLight(std::make_shared<PointLight>(Vector3(3, 5, 0), Vector3(0.8, 0.8, 0.8)));
+        scene.addLight(std::make_shared<PointLight>(Vector3(-4, 3, 2), Vector3(0.4, 0.4, 0.5)));
+        keep(compare("whitted_linear", scene, camera, W, H, RayTracer::PHONG, RayTracer::REINHARD, 6, 1.3, dir));
+        scene.buildBVH();
+        keep(compare("whitted_bvh", scene, camera, W, H, RayTracer::PHONG, RayTracer::UNCHARTED2, 6, 1.0, dir));
+    }
+    return worst;
 }
