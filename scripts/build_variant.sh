@@ -2,7 +2,7 @@
 # A/B build of the device library with extra compiler flags:
 #   scripts/build_variant.sh <name> [flags...]  -> raytracer_amd/csrc/variants/libraytracer_amd_<name>.so
 # (load it with RT_AMD_LIB=<path>).  Only the translation units named in TUS are recompiled with the flags
-# (default: k_pathwave; constants the host side reads too, like RT_PQ_WAVES, need render_hip as well); the others are taken from the production build.
+# (default: k_pathwave; constants the host side reads too, like RT_PQ_STATS, need render_hip as well); the others are taken from the production build.
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../raytracer_amd/csrc"
