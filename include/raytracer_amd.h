@@ -305,8 +305,10 @@ int rt_get_stats(rt_context* ctx, rt_stats* out);
  * rt_context + stream per device, the scene replicated; a frame is partitioned as SURVEY.md 8(e) lays out --
  * Whitted / binary: 8-row bands dealt round-robin, each member's bands copied into the frame on devices[0] by one
  * strided peer copy over xGMI (as PPM bytes for rt_group_render_u8); path trace: strata ranges, the members' radiance
- * sums added on devices[0] in member order before the non-linear stages of RayTracer.cpp:301-315.  The frame equals the
- * one-device frame (bit for bit for Whitted; to fp summation order, ~1e-16 relative, for path-trace sums).
+ * sums combined as a reduce-scatter by peer reads -- member j adds slice j of every member's sums in member order, before
+ * the non-linear stages of RayTracer.cpp:301-315, applies those stages to its slice and copies the finished slice to
+ * devices[0].  The frame equals the one-device frame (bit for bit for Whitted; to fp summation order, ~1e-16 relative,
+ * for path-trace sums).  Every pair of distinct listed devices needs peer access (rt_group_create fails otherwise).
  * The same device may be listed more than once (members then share it).  Pass whole-frame params. */
 typedef struct rt_group rt_group;
 int rt_group_create(rt_group** out, const int* devices, int n_devices);
