@@ -11,6 +11,7 @@ import numpy as np
 import raytracer_amd as rt
 from tests import oracle_lib, scene_util
 
+heavy = os.environ.get("FUZZ_HEAVY") == "1"  # fewer, larger path-traced frames with deep glass: full queues, many jobs per wave
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 r = rt.Renderer(0)
@@ -21,11 +22,13 @@ seed = seed0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     mode = [rt.RT_MODE_PHONG, rt.RT_MODE_PATHTRACE, rt.RT_MODE_PATHTRACE, rt.RT_MODE_BINARY][int(rng.integers(0, 4))]
+    if heavy:
+        mode = rt.RT_MODE_PATHTRACE
     n_sph, n_tri, n_cyl = (int(rng.integers(0, k)) for k in (40, 30, 12))
     if n_sph + n_tri + n_cyl == 0:
         n_sph = 1
     types, geom = scene_util.random_prims(rng, n_sph, n_tri, n_cyl, extent=float(rng.uniform(1.5, 5.0)))
-    if rng.random() < 0.3:  # something around everything: long ray trees
+    if rng.random() < (0.7 if heavy else 0.3):  # something around everything: long ray trees
         shell = np.zeros((1, geom.shape[1])); shell[0, 3] = 9.0
         types = np.concatenate([np.array([rt.capi.RT_SPHERE], dtype=np.int32), types]); geom = np.concatenate([shell, geom])
     mats = [scene_util.default_material(diffuse=tuple(rng.uniform(0.1, 0.9, 3)), ks=float(rng.uniform(0, 0.6)), kd=float(rng.uniform(0.3, 1.0)),
@@ -51,7 +54,10 @@ while time.time() - t0 < budget:
                              aperture=float(rng.uniform(0, 0.3)) if (pt and rng.random() < 0.3) else 0.0)
     spp = int(rng.choice([1, 4, 5, 9, 16, 36]))
     ls = int(rng.choice([1, 2, 4, 8, 16, 16, 32, 3]))
-    P = scene_util.make_params(w, h, mode=mode, max_depth=int(rng.integers(0, 11)), pixel_samples=spp, light_samples=ls,
+    if heavy:
+        w, h = int(rng.integers(150, 420)), int(rng.integers(100, 300))
+        spp, ls = int(rng.choice([16, 64, 100])), int(rng.choice([16, 16, 4]))
+    P = scene_util.make_params(w, h, mode=mode, max_depth=int(rng.integers(6, 17)) if heavy else int(rng.integers(0, 11)), pixel_samples=spp, light_samples=ls,
                                tonemap=int(rng.integers(0, 4)), exposure=float(rng.uniform(0.5, 2.0)), seed=int(rng.integers(0, 1 << 30)))
     what = "seed %d mode %d prims %d/%d/%d bvh %d %dx%d depth %d spp %d ls %d lights %d" % (
         seed, mode, n_sph, n_tri, n_cyl, syn.desc.use_bvh, w, h, P.max_depth, spp, ls, len(lights))
