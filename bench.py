@@ -400,7 +400,7 @@ class Bench:
                  "data": "reference scene file (scenes/pathtrace.json), resized",
                  "config": {"workload": "pathtrace.json 1920x1080, pixelSamples %d (%dx%d strata), lightSamples %d, nbounces 8"
                                         % (spp, side, side, PT_LIGHT_SAMPLES),
-                            "rays_per_step": rays, "parallelism": "strata-range x%d + RCCL reduce" % self.world},
+                            "rays_per_step": rays, "parallelism": "strata-range x%d + RCCL reduce-scatter, stages per slice, gather" % self.world},
                  "roofline": roof}
         return block, (sf, desc, base)
 
