@@ -16,10 +16,11 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 r = rt.Renderer(0)
 t0 = t_last = time.time()
-n_cases = n_bad = 0
+n_cases = n_bad = n_group = 0
 kinds = {}
 seed = seed0
-while time.time() - t0 < budget:
+one = os.environ.get("FUZZ_ONE") == "1"  # exactly one case (the first seed), reported whatever its outcome
+while time.time() - t0 < budget or (one and n_cases == 0):
     rng = np.random.default_rng(seed)
     mode = [rt.RT_MODE_PHONG, rt.RT_MODE_PATHTRACE, rt.RT_MODE_PATHTRACE, rt.RT_MODE_BINARY][int(rng.integers(0, 4))]
     if heavy:
@@ -36,8 +37,31 @@ while time.time() - t0 < budget:
             scene_util.default_material(reflective=1, reflectivity=float(rng.uniform(0.1, 1.0))),
             scene_util.default_material(refractive=1, ior=float(rng.uniform(1.05, 2.0))),
             scene_util.default_material(diffuse=tuple(rng.uniform(0.1, 0.9, 3)), exp=int(rng.integers(1, 30)))]
+    textures = None
+    if rng.random() < 0.3:  # a random texture on the first and the last material (getUV of every primitive class, getTextureColor)
+        textures = [rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 3)).astype(np.uint8)]
+        mats[0].texture = 0
+        mats[3].texture = 0
+    if os.environ.get("FUZZ_TEX_CONST") == "1" and textures is not None:  # (investigations: every texel the same colour)
+        textures = [np.broadcast_to(textures[0][0, 0], textures[0].shape).copy()]
+    if os.environ.get("FUZZ_NOTEX") == "1" and textures is not None:  # (investigations: the same scene without its texture)
+        textures = None
+        mats[0].texture = -1
+        mats[3].texture = -1
     pm = rng.integers(0, len(mats), len(types))
     pt = mode == rt.RT_MODE_PATHTRACE
+    # getUV on a cylinder's TOP cap is a coin toss of the hit point's last bit: v = clamp(y / height, 0, 1) is 1 or 1 - 1e-16
+    # there, and getTextureColor maps the one to the texture's last row (v - floor(v) = 0 -> (1 - 0) h, clamped) and the other
+    # to its first.  Library and oracle toss the same coin for the same point (Whitted frames: exact), but a path tracer's
+    # points carry the last-bit differences of cos / sin from the first diffuse bounce on.  So path-traced cases keep
+    # textures off their cylinders (strict criterion), except one in ten, which is held to a loose one.
+    loose = False
+    if pt and textures is not None:
+        cyl_tex = (types == rt.capi.RT_CYLINDER) & ((pm == 0) | (pm == 3))
+        if rng.random() < 0.1:
+            loose = bool(cyl_tex.any())
+        else:
+            pm[cyl_tex] = 1 + (pm[cyl_tex] & 1)
     if pt or rng.random() < 0.3:
         n = rng.normal(size=3); n /= np.linalg.norm(n)
         u = np.cross(n, rng.normal(size=3)); u /= np.linalg.norm(u)
@@ -48,7 +72,7 @@ while time.time() - t0 < budget:
         lights = [scene_util.point_light(tuple(rng.uniform(-6, 6, 3))) for _ in range(int(rng.integers(1, 4)))]
     if pt and rng.random() < 0.15:
         lights = [scene_util.point_light(tuple(rng.uniform(-6, 6, 3)))]
-    syn = scene_util.SyntheticScene(types, geom, materials=mats, lights=lights, use_bvh=int(rng.integers(0, 2)), prim_material=pm)
+    syn = scene_util.SyntheticScene(types, geom, materials=mats, lights=lights, use_bvh=int(rng.integers(0, 2)), prim_material=pm, textures=textures)
     w, h = int(rng.integers(8, 140)), int(rng.integers(8, 100))
     cam = scene_util.look_at(tuple(rng.uniform(-6, 6, 3)), tuple(rng.uniform(-1, 1, 3)), aspect=w / h,
                              aperture=float(rng.uniform(0, 0.3)) if (pt and rng.random() < 0.3) else 0.0)
@@ -59,6 +83,8 @@ while time.time() - t0 < budget:
         spp, ls = int(rng.choice([16, 64, 100])), int(rng.choice([16, 16, 4]))
     P = scene_util.make_params(w, h, mode=mode, max_depth=int(rng.integers(6, 17)) if heavy else int(rng.integers(0, 11)), pixel_samples=spp, light_samples=ls,
                                tonemap=int(rng.integers(0, 4)), exposure=float(rng.uniform(0.5, 2.0)), seed=int(rng.integers(0, 1 << 30)))
+    if os.environ.get("FUZZ_DEPTH"):  # (investigations: the same case with another recursion limit)
+        P.max_depth = int(os.environ["FUZZ_DEPTH"])
     what = "seed %d mode %d prims %d/%d/%d bvh %d %dx%d depth %d spp %d ls %d lights %d" % (
         seed, mode, n_sph, n_tri, n_cyl, syn.desc.use_bvh, w, h, P.max_depth, spp, ls, len(lights))
     try:
@@ -67,22 +93,65 @@ while time.time() - t0 < budget:
         st = r.stats()
         orgb, ohit, cnt, _ = oracle_lib.render(syn.desc, cam, P, want_hit=not pt)
         if pt:
-            frac = float((np.abs(rgb - orgb).max(axis=2) > 1e-9).mean())
-            ok = frac <= 1e-3 + 2.0 / (w * h) and abs(st.rays - cnt["rays"]) <= 1e-3 * cnt["rays"] + 64 and bool(np.isfinite(rgb).all())
-            detail = "frac %.2e rays %d / %d" % (frac, st.rays, cnt["rays"])
+            dpx = (np.abs(rgb - orgb) / np.maximum(1.0, np.abs(orgb))).max(axis=2)  # (relative where a small, near light makes the radiance large)
+            frac = float((dpx > 1e-9).mean())
+            lim = 1e-2 if loose else 1e-3
+            ok = (frac <= lim + 2.0 / (w * h) and abs(st.rays - cnt["rays"]) <= 1e-3 * cnt["rays"] + 64 and bool(np.isfinite(rgb).all()))
+            detail = "frac %.2e largest %.2e rays %d / %d" % (frac, float(dpx.max()), st.rays, cnt["rays"])
         else:
             ok = bool(np.array_equal(hit, ohit)) and st.rays == cnt["rays"] and float(np.abs(rgb - orgb).max()) <= 1e-12
             detail = "hits equal %s rays %d / %d max diff %.2e" % (bool(np.array_equal(hit, ohit)), st.rays, cnt["rays"], float(np.abs(rgb - orgb).max()))
+        if ok and not heavy and rng.random() < 0.1:  # the same frame from a group of 2-4 members on this device
+            class _SF:  # (what Group.load reads)
+                pass
+            sfl = _SF(); sfl.camera = cam; sfl.desc = syn.desc; sfl.params = P
+            g = rt.Group([0] * int(rng.integers(2, 5)))
+            try:
+                g.load(sfl, P)
+                grgb, ghit = g.render(want_hit=not pt)
+            finally:
+                g.close()
+            n_group += 1
+            if pt:
+                ok = float(np.abs(grgb - rgb).max()) < 1e-12
+            else:
+                ok = bool(np.array_equal(grgb, rgb)) and bool(np.array_equal(ghit, hit))
+            if not ok:
+                detail = "group frame differs from the one-context frame (max %.2e)" % float(np.abs(grgb - rgb).max())
     except Exception as e:  # a refused configuration is a finding too
         ok, detail = False, "raised %s" % e
     n_cases += 1
     kinds[mode] = kinds.get(mode, 0) + 1
-    if not ok:
-        n_bad += 1
-        print("FAIL", what, "|", detail, flush=True)
+    if not ok or one:
+        n_bad += 0 if ok else 1
+        print("FAIL" if not ok else "ok", what, "|", detail, "| textured %s" % (textures is not None), flush=True)
+    if one:
+        d = np.abs(rgb - orgb).max(axis=2)
+        ys, xs = np.nonzero(d > 1e-9)
+        for y, x in list(zip(ys, xs))[:3]:
+            print("   pixel (%d, %d): library %s oracle %s" % (y, x, rgb[y, x].tolist(), orgb[y, x].tolist()))
+        print("pixels off: %d of %d; largest %.3e; first few (y, x, diff): %s" % (len(ys), d.size, float(d.max()), [(int(y), int(x), float(d[y, x])) for y, x in list(zip(ys, xs))[:8]]))
+        # getUV + getTextureColor of this scene's primitives at the hit points of random rays: library against oracle
+        rr = np.random.default_rng(seed + 7)
+        no = 400000
+        oo = rr.uniform(-6, 6, (no, 3)); dd = rr.normal(size=(no, 3)); dd /= np.linalg.norm(dd, axis=1)[:, None]
+        tt, pp, _ = r.trace_rays(oo, dd)
+        keep = pp >= 0
+        pts = oo[keep] + dd[keep] * tt[keep][:, None]
+        pr = pp[keep]
+        got = r.optics(2, np.column_stack([pr.astype(np.float64), pts]))
+        want = oracle_lib.uv_texture(syn.desc, pr, points=pts)
+        du = np.abs(got[:, 0:2] - want[:, 0:2]).max(axis=1)
+        dc = np.abs(got[:, 2:5] - want[:, 2:5]).max(axis=1)
+        bad = np.nonzero(dc > 0)[0]
+        print("uv / texture at %d hit points: max |duv| %.2e, texture colour differs at %d points" % (len(pr), float(du.max()), len(bad)))
+        for k in bad[:6]:
+            print("   prim %d type %d point %s: uv got %s want %s colour got %s want %s" % (pr[k], types[pr[k]], pts[k], got[k, 0:2], want[k, 0:2], got[k, 2:5], want[k, 2:5]))
+        print("primitive types:", dict(zip(*np.unique(types, return_counts=True))), "materials of prims:", dict(zip(*np.unique(pm, return_counts=True))))
+        break
     seed += 1
     if time.time() - t_last > 30.0:  # (a long run that prints nothing looks hung to the box)
         t_last = time.time()
         print("... %d cases, %d failed, %.0f s" % (n_cases, n_bad, t_last - t0), flush=True)
-print("%d cases (by mode %s) in %.0f s, %d failed; seeds %d..%d" % (n_cases, kinds, time.time() - t0, n_bad, seed0, seed - 1))
+print("%d cases (by mode %s; %d also through a group) in %.0f s, %d failed; seeds %d..%d" % (n_cases, kinds, n_group, time.time() - t0, n_bad, seed0, seed - 1))
 sys.exit(1 if n_bad else 0)

@@ -47,7 +47,7 @@ def test_level_kernel_and_queue_kernel_agree():
 
 
 def test_frame_does_not_depend_on_how_roots_are_dealt(monkeypatch):
-    """A pixel's terms are summed exactly (96-bit fixed point) and rounded once: job size, the golden-ratio dealing order,
+    """A pixel's terms are summed exactly (128-bit fixed point) and rounded once: job size, the golden-ratio dealing order,
     the cost-ordered job table, the frame's repetition and the kernel's instantiation (12 or 16 waves per workgroup) must
     not change a bit."""
     r = _make({})
@@ -116,17 +116,17 @@ def test_many_bounces_and_glass_everywhere(renderer):
 
 def test_exact_accumulator_arithmetic(renderer):
     """rt_debug_math op 14: a + b + 3a - b through pq_fixed / pq_acc_value.  Terms are truncated towards zero to multiples
-    of 2^-64, added as integers and rounded to nearest-even once."""
+    of 2^-96, added as integers and rounded to nearest-even once."""
     rng = np.random.default_rng(11)
     n = 20000
-    a = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-70, 28, n)) * rng.choice([-1.0, 1.0], n)
-    b = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-70, 28, n)) * rng.choice([-1.0, 1.0], n)
-    a[:8] = [0.0, 1.0, -1.0, 2.0 ** -64, 2.0 ** -65, 1.0 + 2.0 ** -52, 3.0, 2.0 ** 28]  # (the accumulator holds |sum| < 2^31)
-    b[:8] = [0.0, 2.0 ** -53, 2.0 ** -53, 2.0 ** -64, -(2.0 ** -64), 2.0 ** -60, -3.0, 2.0 ** -64]
+    a = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-102, 28, n)) * rng.choice([-1.0, 1.0], n)
+    b = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-102, 28, n)) * rng.choice([-1.0, 1.0], n)
+    a[:8] = [0.0, 1.0, -1.0, 2.0 ** -96, 2.0 ** -97, 1.0 + 2.0 ** -52, 3.0, 2.0 ** 28]  # (the accumulator holds |sum| < 2^31)
+    b[:8] = [0.0, 2.0 ** -53, 2.0 ** -53, 2.0 ** -96, -(2.0 ** -96), 2.0 ** -60, -3.0, 2.0 ** -96]
     got = renderer.math(14, a, b)
-    one = Fraction(2) ** 64
+    one = Fraction(2) ** 96
 
-    def trunc(x):  # towards zero to a multiple of 2^-64
+    def trunc(x):  # towards zero to a multiple of 2^-96
         f = Fraction(float(x)) * one
         return Fraction(int(f)) / one   # int() truncates towards zero
 
@@ -136,7 +136,7 @@ def test_exact_accumulator_arithmetic(renderer):
 
 
 def test_mid_sized_scene_takes_the_twelve_wave_kernel(renderer, monkeypatch):
-    """90 primitives: the image leaves 16 waves fewer than 168 accumulator slots each, so pq_kernel runs with 12 waves per
+    """90 primitives: the image leaves 16 waves fewer than 152 accumulator slots each, so pq_kernel runs with 12 waves per
     workgroup (and fewer slots than the tiny scenes get) -- oracle parity, and the level kernel agrees."""
     from tests import oracle_lib
     rng = np.random.default_rng(21)

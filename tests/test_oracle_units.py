@@ -118,3 +118,30 @@ def test_random_rays_linear_vs_bvh_agree_in_oracle_for_plus_y_cylinders():
     t0, p0, _ = oracle_lib.trace_rays(s0.desc, o, d)
     assert np.array_equal(t1, t0)
     assert (p1 >= 0).sum() > 100
+
+
+def test_texture_row_on_a_cylinders_top_cap_hangs_on_the_points_last_bit():
+    """Cylinder getUV: v = clamp(y / height, 0, 1) (src/Cylinder.cpp); Material::getTextureColor wraps v - floor(v) and takes
+    row int((1 - v) h) (src/Material.cpp:69-86).  On the TOP cap y / height is 1 or 1 - 2^-53: the first wraps to 0 and lands
+    in the texture's LAST row, the second in its FIRST.  Which one a hit gets depends on the last bit of its point -- the same
+    on the GPU and in the oracle for the same point (Whitted frames are exact), not for the points of a path tracer after a
+    diffuse bounce, whose cos / sin differ in the last bits between libraries (scripts/gpu_fuzz.py keeps textures off
+    cylinders in path-traced cases for this reason)."""
+    tex = np.zeros((4, 1, 3), dtype=np.uint8)
+    tex[:, 0, 0] = [10, 20, 30, 40]  # row k has red = 10 (k + 1)
+    geom = np.zeros((1, capi.RT_GEOM_STRIDE))
+    geom[0, 0:3] = (0.3, -0.7, 1.1)
+    geom[0, 3:6] = (0.0, 1.0, 0.0)
+    geom[0, 6], geom[0, 7] = 1.0, 1.3
+    mat = scene_util.default_material()
+    mat.texture = 0
+    syn = scene_util.SyntheticScene(np.array([capi.RT_CYLINDER], dtype=np.int32), geom, materials=[mat], textures=[tex])
+    top = geom[0, 1] + geom[0, 7]
+    rng = np.random.default_rng(2)
+    n = 2000
+    pts = np.column_stack([0.3 + rng.uniform(-0.5, 0.5, n), np.full(n, top), 1.1 + rng.uniform(-0.5, 0.5, n)])
+    pts[:, 1] = np.nextafter(pts[:, 1], np.where(rng.random(n) < 0.5, -np.inf, np.inf))  # one ulp below / above the cap's plane
+    out = oracle_lib.uv_texture(syn.desc, np.zeros(n, dtype=np.int32), points=pts)
+    rows = np.rint(out[:, 2] * 255.0 / 10.0).astype(int) - 1
+    assert set(rows.tolist()) == {0, 3}            # never a row in between: the cap's v is 1 up to rounding ...
+    assert 0.2 < (rows == 0).mean() < 0.8          # ... and which end of the texture it means is a toss of the last bit
