@@ -338,7 +338,7 @@ int rt_debug_trace_rays(rt_context* ctx, int64_t n, const double* origins, const
  * normalize((a, b, 0.75 b)) (of normalize((b, 0.75 b, a))), 11 / 12 the x (z) component of (a, 0.75 a, -1.5 a) / b
  * (of (0.75 a, -1.5 a, a) / b) through the shared-reciprocal Vector3 / double, 13 sqrt(a) as Vector3::length takes it
  * (the device library's sequence without its rescaling wrapper where that is the identity), 14 a + b + 3a - b summed in the
- * path tracer's exact 128-bit fixed-point accumulator (every term truncated to a multiple of 2^-96, one rounding at the end). */
+ * path tracer's exact 128-bit fixed-point accumulator (every term truncated to a multiple of 2^-80, one rounding at the end). */
 int rt_debug_math(rt_context* ctx, int op, int64_t n, const double* a, const double* b, double* out);
 /* op 0: n rows in[k] = (I xyz, N xyz, eta_t, eta_i) -> out[k] = (refract xyz, 1 if length(normalize(refract)) > 0 else 0
  * [the transmission test of RayTracer.cpp:572], reflect xyz, fresnel, fresnelReflectance(|I.N|, eta_t)), the device's

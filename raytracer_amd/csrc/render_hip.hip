@@ -233,7 +233,7 @@ __global__ void debug_math_kernel(int op, long long n, const double* a, const do
         case 11: r = div3(mk(x, 0.75 * x, -1.5 * x), y).x; break;  // D3 / double through one shared reciprocal when exact
         case 12: r = div3(mk(0.75 * x, -1.5 * x, x), y).z; break;
         case 13: r = sqrt_windowed(x); break;  // the library's sqrt without its rescaling wrapper when that is the identity
-        case 14: {  // pq_kernel's exact accumulator: x + y + 3 x - y as 128-bit fixed point (each term truncated to 2^-96), rounded once
+        case 14: {  // pq_kernel's exact accumulator: x + y + 3 x - y as 128-bit fixed point (each term truncated to 2^-80), rounded once
             unsigned long long lo = 0, hi = 0, l, h;
             const double t[4] = {x, y, 3.0 * x, -y};
             for (int k = 0; k < 4; ++k) {

@@ -116,17 +116,17 @@ def test_many_bounces_and_glass_everywhere(renderer):
 
 def test_exact_accumulator_arithmetic(renderer):
     """rt_debug_math op 14: a + b + 3a - b through pq_fixed / pq_acc_value.  Terms are truncated towards zero to multiples
-    of 2^-96, added as integers and rounded to nearest-even once."""
+    of 2^-80, added as integers and rounded to nearest-even once."""
     rng = np.random.default_rng(11)
     n = 20000
-    a = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-102, 28, n)) * rng.choice([-1.0, 1.0], n)
-    b = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-102, 28, n)) * rng.choice([-1.0, 1.0], n)
-    a[:8] = [0.0, 1.0, -1.0, 2.0 ** -96, 2.0 ** -97, 1.0 + 2.0 ** -52, 3.0, 2.0 ** 28]  # (the accumulator holds |sum| < 2^31)
-    b[:8] = [0.0, 2.0 ** -53, 2.0 ** -53, 2.0 ** -96, -(2.0 ** -96), 2.0 ** -60, -3.0, 2.0 ** -96]
+    a = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-86, 44, n)) * rng.choice([-1.0, 1.0], n)
+    b = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-86, 44, n)) * rng.choice([-1.0, 1.0], n)
+    a[:8] = [0.0, 1.0, -1.0, 2.0 ** -80, 2.0 ** -81, 1.0 + 2.0 ** -52, 3.0, 2.0 ** 44]  # (the accumulator holds |sum| < 2^47)
+    b[:8] = [0.0, 2.0 ** -53, 2.0 ** -53, 2.0 ** -80, -(2.0 ** -80), 2.0 ** -60, -3.0, 2.0 ** -80]
     got = renderer.math(14, a, b)
-    one = Fraction(2) ** 96
+    one = Fraction(2) ** 80
 
-    def trunc(x):  # towards zero to a multiple of 2^-96
+    def trunc(x):  # towards zero to a multiple of 2^-80
         f = Fraction(float(x)) * one
         return Fraction(int(f)) / one   # int() truncates towards zero
 
