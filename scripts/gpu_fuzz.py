@@ -16,7 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 r = rt.Renderer(0)
 t0 = t_last = time.time()
-n_cases = n_bad = n_group = 0
+n_cases = n_bad = n_group = n_static = 0
 kinds = {}
 seed = seed0
 one = os.environ.get("FUZZ_ONE") == "1"  # exactly one case (the first seed), reported whatever its outcome
@@ -101,6 +101,16 @@ while time.time() - t0 < budget or (one and n_cases == 0):
         else:
             ok = bool(np.array_equal(hit, ohit)) and st.rays == cnt["rays"] and float(np.abs(rgb - orgb).max()) <= 1e-12
             detail = "hits equal %s rays %d / %d max diff %.2e" % (bool(np.array_equal(hit, ohit)), st.rays, cnt["rays"], float(np.abs(rgb - orgb).max()))
+        if ok and not pt and P.max_depth > 0 and rng.random() < 0.1:  # the same frame out of the static workspace, as PPM bytes
+            import torch
+            buf = torch.full((h * w * 3,), 77, dtype=torch.uint8, device="cuda")
+            r.render_device_u8_static(buf.data_ptr(), None, None, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            r.stats()
+            n_static += 1
+            ok = bool(np.array_equal(buf.cpu().numpy().reshape(h, w, 3), (255.999 * rgb).astype(np.int32).astype(np.uint8)))
+            if not ok:
+                detail = "rt_render_device_u8_static differs from the allocating entry point"
         if ok and not heavy and rng.random() < 0.1:  # the same frame from a group of 2-4 members on this device
             class _SF:  # (what Group.load reads)
                 pass
@@ -153,5 +163,5 @@ while time.time() - t0 < budget or (one and n_cases == 0):
     if time.time() - t_last > 30.0:  # (a long run that prints nothing looks hung to the box)
         t_last = time.time()
         print("... %d cases, %d failed, %.0f s" % (n_cases, n_bad, t_last - t0), flush=True)
-print("%d cases (by mode %s; %d also through a group) in %.0f s, %d failed; seeds %d..%d" % (n_cases, kinds, n_group, time.time() - t0, n_bad, seed0, seed - 1))
+print("%d cases (by mode %s; %d also through a group, %d through the static workspace) in %.0f s, %d failed; seeds %d..%d" % (n_cases, kinds, n_group, n_static, time.time() - t0, n_bad, seed0, seed - 1))
 sys.exit(1 if n_bad else 0)
