@@ -384,7 +384,7 @@ class Bench:
                 # ... and with the per-sample arithmetic of the reference priced in (lower bound, see bench.py)
                 "frac_with_sampling": (alg_ops + sample_ops) / self.world / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS,
                 "sampling_ops_per_shadow_ray": 53.0,
-                "kernel": ("pq_kernel (one launch per 256 strata; every wave on its own: ray pass = 64 stacked rays or new roots -> closest "
+                "kernel": ("pq_kernel (one launch per 1024 strata; every wave on its own: ray pass = 64 stacked rays or new roots -> closest "
                            "hit; hit pass = 64 hits -> class dark / clear / general, material branch, child rays; light pass = 4 hits x "
                            "16 samples; exact per-pixel sums added to the frame)") if os.environ.get("RT_PT_QUEUES", "1") != "0" else
                           "pt_kernel (per batch of 4 strata; per depth: trace, classify, light, shade; combine) + bw_accumulate_path_kernel",

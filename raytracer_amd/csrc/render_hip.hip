@@ -309,6 +309,7 @@ struct rt_context {
     unsigned long long pq_order_gen = 0;  // generation whose job order (most expensive first) d_pq_job holds
     unsigned pq_order_jobs = 0;
     int pq_order_batch = 0;
+    unsigned pq_order_min_piece = 0, pq_order_job_roots = 0;  // the order is that of jobs of this size, cut down to pieces of that size
     bool last_was_pq = false;
     int last_launches = 1;  // launches of the frame's main kernel in the last render (rt_stats.kernel_launches)
     bool pt_generic = false;     // RT_PT_GENERIC=1: path trace with bw_kernel<1> (any lights / sample counts) even where pt_kernel applies

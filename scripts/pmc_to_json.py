@@ -50,8 +50,8 @@ out = {"workload": "clutter_500_4k, one frame at a time (scripts/gpu_prof_case.p
 json.dump(out, open(os.path.join(ROOT, "profiles", rnd + "_clutter_500_pmc.json"), "w"), indent=1)
 t = load(os.path.join(d, "pmc_pathtrace.csv"))
 k, name = find(t, "pq_kernel") if any(x.startswith("pq_kernel") for x in t) else find(t, "pt_kernel")
-out = {"workload": "pathtrace.json 1920x1080, lightSamples 16, one launch = 256 strata (scripts/gpu_prof_case.py pathtrace 1920 1080 2 spp256)",
-       "kernel": name, "strata_per_launch": 256,
+out = {"workload": "pathtrace.json 1920x1080, lightSamples 16, one launch = 1024 strata (scripts/gpu_prof_case.py pathtrace 1920 1080 2 spp1024)",
+       "kernel": name, "strata_per_launch": 1024,
        "hbm_bytes_per_launch": k["fetch_bytes_upper"] + k["write_bytes"], "hbm_bytes_per_launch_fetch_raw": k["fetch_bytes_raw"] + k["write_bytes"],
        "valu_busy": k["valu_busy"], "lane_utilisation": k["lane_utilisation"], name.split("<")[0]: k, "source": src % "pathtrace"}
 json.dump(out, open(os.path.join(ROOT, "profiles", rnd + "_pathtrace_pmc.json"), "w"), indent=1)
